@@ -1,0 +1,309 @@
+"""Graph-of-convex-sets set-up feeding the ADMM hot path (host side, runs once).
+
+Mirrors the reference's set-up helpers:
+  * ``convert_pt_to_polytope``  -- reference utils.py:12-28
+  * ``build_graph``             -- reference utils.py:31-82 (edge iff the two
+    polytopes intersect, ordered pairs in double-loop order, incidence lists
+    in edge order)
+  * ``delta``                   -- reference utils.py:85-98
+
+and adds what the device path needs and the reference never materialises:
+integer vertex ids, the CSR incidence layout (``I_v_in[v] + I_v_out[v]`` order,
+reference admm_solver_v3.py:107,371), a polytope CSR, and a strictly interior
+point per polytope (used as the interior-point start of the vertex solver).
+
+The reference decides intersection with one LP feasibility solve per ordered
+pair through Drake (utils.py:49-65).  Here: exact interval test when both sets
+are axis-aligned boxes, otherwise an LP feasibility solve with scipy/HiGHS.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, Hashable, List, Sequence, Tuple
+
+import numpy as np
+
+__all__ = [
+    "convert_pt_to_polytope", "build_graph", "delta", "polytopes_overlap",
+    "chebyshev_center", "GcsGraph", "graph_from_sets", "lattice_boxes",
+]
+
+
+def convert_pt_to_polytope(pt, eps=1e-6):
+    """Point -> box of half-width ``eps`` as ``A x <= b`` (reference utils.py:12-28)."""
+    pt = np.asarray(pt, dtype=float)
+    n = len(pt)
+    A = np.vstack([np.eye(n), -np.eye(n)])
+    b = np.hstack([pt + eps, -pt + eps])
+    return A, b
+
+
+def delta(v1, v2):
+    """delta_{v1,v2} of the GCS formulation (reference utils.py:85-98): 1 only for
+    the literal keys ``'s','s'`` or ``'t','t'``."""
+    if (isinstance(v1, str) and isinstance(v2, str)) and (v1 == v2 == 's' or v1 == v2 == 't'):
+        return 1
+    return 0
+
+
+def _as_box(A: np.ndarray, b: np.ndarray):
+    """Return (lo, hi) if ``A x <= b`` is an axis-aligned box written with +-unit
+    rows covering every coordinate on both sides, else None."""
+    m, n = A.shape
+    lo = np.full(n, -np.inf)
+    hi = np.full(n, np.inf)
+    for j in range(m):
+        nz = np.nonzero(A[j])[0]
+        if len(nz) != 1:
+            return None
+        k = nz[0]
+        a = A[j, k]
+        if a > 0:
+            hi[k] = min(hi[k], b[j] / a)
+        else:
+            lo[k] = max(lo[k], b[j] / a)
+    if not (np.all(np.isfinite(lo)) and np.all(np.isfinite(hi))):
+        return None
+    return lo, hi
+
+
+def polytopes_overlap(A1, b1, A2, b2, tol=1e-9) -> bool:
+    """True iff {A1 x <= b1} and {A2 x <= b2} share a point (reference
+    utils.py:49-65 ``check_overlap``).  Touching sets count as overlapping, as
+    they do for an LP feasibility solve."""
+    A1 = np.asarray(A1, float); A2 = np.asarray(A2, float)
+    b1 = np.asarray(b1, float); b2 = np.asarray(b2, float)
+    bx1, bx2 = _as_box(A1, b1), _as_box(A2, b2)
+    if bx1 is not None and bx2 is not None:
+        lo = np.maximum(bx1[0], bx2[0]); hi = np.minimum(bx1[1], bx2[1])
+        return bool(np.all(lo <= hi + tol))
+    from scipy.optimize import linprog
+    A = np.vstack([A1, A2]); b = np.hstack([b1, b2])
+    res = linprog(np.zeros(A.shape[1]), A_ub=A, b_ub=b,
+                  bounds=[(None, None)] * A.shape[1], method="highs")
+    return bool(res.status == 0)
+
+
+def build_graph(As: Dict[Hashable, np.ndarray], bs: Dict[Hashable, np.ndarray]):
+    """Vertex list, directed edge list and incidence lists, with the reference's
+    ordering (utils.py:31-82): ``V = list(As.keys())``; ``E`` = ordered pairs
+    ``(v1, v2)``, ``v1 != v2``, in double-loop order, whose sets intersect;
+    ``I_v_out[v]`` / ``I_v_in[v]`` in ``E`` order."""
+    vertices = list(As.keys())
+    nv = len(vertices)
+    ov = np.zeros((nv, nv), dtype=bool)
+    for i in range(nv):
+        for j in range(i + 1, nv):
+            ov[i, j] = ov[j, i] = polytopes_overlap(As[vertices[i]], bs[vertices[i]],
+                                                    As[vertices[j]], bs[vertices[j]])
+    edges = [(vertices[i], vertices[j]) for i in range(nv) for j in range(nv)
+             if i != j and ov[i, j]]
+    I_v_in = {v: [] for v in vertices}
+    I_v_out = {v: [] for v in vertices}
+    for e in edges:
+        v, w = e
+        I_v_out[v].append(e)
+        I_v_in[w].append(e)
+    return vertices, edges, I_v_in, I_v_out
+
+
+def chebyshev_center(A: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """A strictly interior point of the bounded polytope ``A x <= b`` (centre of
+    the largest inscribed ball); boxes are answered exactly."""
+    A = np.asarray(A, float); b = np.asarray(b, float)
+    bx = _as_box(A, b)
+    if bx is not None:
+        return 0.5 * (bx[0] + bx[1])
+    from scipy.optimize import linprog
+    m, n = A.shape
+    nrm = np.linalg.norm(A, axis=1)
+    c = np.zeros(n + 1); c[-1] = -1.0
+    res = linprog(c, A_ub=np.hstack([A, nrm[:, None]]), b_ub=b,
+                  bounds=[(None, None)] * n + [(0, None)], method="highs")
+    if res.status != 0 or res.x[-1] <= 0:
+        raise ValueError("polytope has no interior (or is unbounded)")
+    return res.x[:n]
+
+
+@dataclasses.dataclass
+class GcsGraph:
+    """Integer-id description of one GCS instance in the layout the C-ABI takes
+    (include/gcsadmm.h ``gcsadmm_graph_desc``).
+
+    Incidence ``k`` in ``inc_ptr[v] .. inc_ptr[v+1]`` lists first the incoming
+    then the outgoing edges of ``v`` (reference admm_solver_v3.py:107,371);
+    ``inc_edge[k]`` is the directed edge id, ``inc_out[k]`` is 1 when ``v`` is the
+    tail.  ``edge_inc_tail[e]`` / ``edge_inc_head[e]`` are the incidence slots of
+    edge ``e`` at its tail / head, i.e. where the two vertex copies of the
+    edge's coupled words live."""
+    n: int
+    keys: List[Hashable]
+    edge_tail: np.ndarray          # int32 [E]
+    edge_head: np.ndarray          # int32 [E]
+    inc_ptr: np.ndarray            # int32 [V+1]
+    inc_edge: np.ndarray           # int32 [2E]
+    inc_out: np.ndarray            # int32 [2E]
+    edge_inc_tail: np.ndarray      # int32 [E]
+    edge_inc_head: np.ndarray      # int32 [E]
+    poly_ptr: np.ndarray           # int32 [V+1]
+    poly_A: np.ndarray             # float64 [sum m, n]
+    poly_b: np.ndarray             # float64 [sum m]
+    interior: np.ndarray           # float64 [V, n]
+    src: int
+    dst: int
+
+    @property
+    def num_vertices(self) -> int:
+        return len(self.keys)
+
+    @property
+    def num_edges(self) -> int:
+        return len(self.edge_tail)
+
+    @property
+    def c(self) -> int:
+        """coupled words per (edge, endpoint) copy: z_{e,u}[:n], z_{e,w}[:n], y_e"""
+        return 2 * self.n + 1
+
+    # sizes of the reference's flat vectors (admm_solver_v3.py:89-133,154-172)
+    @property
+    def nx(self) -> int:
+        return (4 * self.n + 1) * (self.num_vertices + 2 * self.num_edges)
+
+    @property
+    def nz(self) -> int:
+        return (4 * self.n + 1) * self.num_edges
+
+    @property
+    def nmu(self) -> int:
+        return (4 * self.n + 2) * self.num_edges
+
+    def edges_as_keys(self) -> List[Tuple[Hashable, Hashable]]:
+        return [(self.keys[u], self.keys[w]) for u, w in zip(self.edge_tail, self.edge_head)]
+
+    def algorithmic_bytes_per_iteration(self, word_bytes: int) -> float:
+        """w * (14 c |E| + |V| mbar (n+1))."""
+        m_total = int(self.poly_ptr[-1])
+        return word_bytes * (14.0 * self.c * self.num_edges + m_total * (self.n + 1))
+
+
+def _finish_graph(n, keys, edge_tail, edge_head, poly_list, interior, src, dst) -> GcsGraph:
+    nv = len(keys)
+    edge_tail = np.asarray(edge_tail, dtype=np.int32)
+    edge_head = np.asarray(edge_head, dtype=np.int32)
+    ne = len(edge_tail)
+    deg_in = np.bincount(edge_head, minlength=nv)
+    deg_out = np.bincount(edge_tail, minlength=nv)
+    inc_ptr = np.zeros(nv + 1, dtype=np.int64)
+    inc_ptr[1:] = np.cumsum(deg_in + deg_out)
+    inc_edge = np.zeros(2 * ne, dtype=np.int32)
+    inc_out = np.zeros(2 * ne, dtype=np.int32)
+    edge_inc_tail = np.zeros(ne, dtype=np.int32)
+    edge_inc_head = np.zeros(ne, dtype=np.int32)
+    # incoming first, in edge order (stable sort keeps edge order)
+    order_in = np.argsort(edge_head, kind="stable")
+    pos_in = inc_ptr[:-1][edge_head[order_in]] + (np.arange(ne) - np.concatenate(
+        [[0], np.cumsum(deg_in)])[edge_head[order_in]])
+    inc_edge[pos_in] = order_in
+    inc_out[pos_in] = 0
+    edge_inc_head[order_in] = pos_in
+    order_out = np.argsort(edge_tail, kind="stable")
+    pos_out = inc_ptr[:-1][edge_tail[order_out]] + deg_in[edge_tail[order_out]] + (
+        np.arange(ne) - np.concatenate([[0], np.cumsum(deg_out)])[edge_tail[order_out]])
+    inc_edge[pos_out] = order_out
+    inc_out[pos_out] = 1
+    edge_inc_tail[order_out] = pos_out
+    ms = np.array([A.shape[0] for A, _ in poly_list], dtype=np.int64)
+    poly_ptr = np.zeros(nv + 1, dtype=np.int64)
+    poly_ptr[1:] = np.cumsum(ms)
+    poly_A = np.ascontiguousarray(np.vstack([np.asarray(A, float).reshape(-1, n) for A, _ in poly_list]))
+    poly_b = np.ascontiguousarray(np.hstack([np.asarray(b, float).ravel() for _, b in poly_list]))
+    return GcsGraph(n=n, keys=list(keys), edge_tail=edge_tail, edge_head=edge_head,
+                    inc_ptr=inc_ptr.astype(np.int32), inc_edge=inc_edge, inc_out=inc_out,
+                    edge_inc_tail=edge_inc_tail, edge_inc_head=edge_inc_head,
+                    poly_ptr=poly_ptr.astype(np.int32), poly_A=poly_A, poly_b=poly_b,
+                    interior=np.ascontiguousarray(interior, dtype=float), src=int(src), dst=int(dst))
+
+
+def graph_from_sets(As, bs, n, edges=None) -> GcsGraph:
+    """Build the integer/CSR description from a reference-style case
+    (``As``, ``bs`` dicts with mandatory keys ``'s'`` and ``'t'``,
+    test_data/test1.py:26-33).  ``edges`` (list of key pairs) may be supplied to
+    skip the O(|V|^2) overlap tests."""
+    keys = list(As.keys())
+    if 's' not in As or 't' not in As:
+        raise KeyError("case must define vertices 's' and 't'")
+    index = {k: i for i, k in enumerate(keys)}
+    if edges is None:
+        _, edges, _, _ = build_graph(As, bs)
+    tail = [index[u] for u, _ in edges]
+    head = [index[w] for _, w in edges]
+    polys = [(np.asarray(As[k], float), np.asarray(bs[k], float)) for k in keys]
+    interior = np.stack([chebyshev_center(A, b) for A, b in polys])
+    return _finish_graph(int(n), keys, tail, head, polys, interior, index['s'], index['t'])
+
+
+def lattice_boxes(nx_cells: int, ny_cells: int, n: int = 2, seed: int = 0,
+                  row_range: Tuple[int, int] | None = None) -> GcsGraph:
+    """Synthetic brick-lattice box GCS of SURVEY.md section 8(d) (configs C3-C5).
+
+    ``nx_cells x ny_cells`` boxes, centre ``(i + 0.5 (j mod 2) + xi, j + eta)``,
+    ``xi, eta ~ U(-.05, .05)``, full width ``~U(.78, .88)``, full height
+    ``~U(1.15, 1.25)``; dims 2..n-1 (if any) are intervals
+    ``[-1 - U(0,.1), 1 + U(0,.1)]``.  Each interior box overlaps exactly its four
+    neighbours in rows j+-1.  ``s`` / ``t`` are the centres of cells (0,0) and
+    (nx-1, ny-1) as point vertices.  Vertex order: ``s, t, cells row-major (j
+    outer, i inner)``; edges in the reference's double-loop order restricted to
+    the (exactly known) overlapping pairs.  Edges are found with the exact
+    interval test on candidate neighbours only, never O(|V|^2).
+    """
+    rng = np.random.default_rng(seed)
+    I, J = np.meshgrid(np.arange(nx_cells), np.arange(ny_cells), indexing="xy")  # [ny, nx]
+    xi = rng.uniform(-0.05, 0.05, size=I.shape)
+    eta = rng.uniform(-0.05, 0.05, size=I.shape)
+    wid = rng.uniform(0.78, 0.88, size=I.shape)
+    hei = rng.uniform(1.15, 1.25, size=I.shape)
+    cx = I + 0.5 * (J % 2) + xi
+    cy = J + eta
+    ncell = nx_cells * ny_cells
+    lo = np.zeros((ncell, n)); hi = np.zeros((ncell, n))
+    lo[:, 0] = (cx - wid / 2).ravel(); hi[:, 0] = (cx + wid / 2).ravel()
+    lo[:, 1] = (cy - hei / 2).ravel(); hi[:, 1] = (cy + hei / 2).ravel()
+    for k in range(2, n):
+        lo[:, k] = -1.0 - rng.uniform(0, 0.1, size=ncell)
+        hi[:, k] = 1.0 + rng.uniform(0, 0.1, size=ncell)
+    cen = 0.5 * (lo + hi)
+    s_pt = cen[0].copy(); t_pt = cen[ncell - 1].copy()
+    eps = 1e-6
+    lo_all = np.vstack([s_pt - eps, t_pt - eps, lo])
+    hi_all = np.vstack([s_pt + eps, t_pt + eps, hi])
+    nv = ncell + 2
+
+    # candidate neighbours on the lattice: rows j-1, j, j+1, columns i-1..i+1
+    cid = lambda i, j: 2 + j * nx_cells + i
+    pairs = []
+    for dj in (-1, 0, 1):
+        for di in (-1, 0, 1):
+            if dj == 0 and di == 0:
+                continue
+            i2 = I + di; j2 = J + dj
+            ok = (i2 >= 0) & (i2 < nx_cells) & (j2 >= 0) & (j2 < ny_cells)
+            a = (2 + J * nx_cells + I)[ok]; bb = (2 + j2 * nx_cells + i2)[ok]
+            pairs.append(np.stack([a, bb], 1))
+    pairs = np.concatenate(pairs)
+    # s / t against the 3x3 cells around their host cell
+    for pid, (ci, cj) in ((0, (0, 0)), (1, (nx_cells - 1, ny_cells - 1))):
+        for dj in (-1, 0, 1):
+            for di in (-1, 0, 1):
+                i2, j2 = ci + di, cj + dj
+                if 0 <= i2 < nx_cells and 0 <= j2 < ny_cells:
+                    pairs = np.vstack([pairs, [[pid, cid(i2, j2)], [cid(i2, j2), pid]]])
+    u, w = pairs[:, 0], pairs[:, 1]
+    ov = np.all(np.maximum(lo_all[u], lo_all[w]) <= np.minimum(hi_all[u], hi_all[w]) + 1e-9, axis=1)
+    pairs = pairs[ov]
+    pairs = np.unique(pairs, axis=0)           # sorts by (tail, head) == double-loop order
+    A_box = np.vstack([np.eye(n), -np.eye(n)])
+    polys = [(A_box, np.hstack([hi_all[v], -lo_all[v]])) for v in range(nv)]
+    keys: List[Hashable] = ['s', 't'] + list(range(ncell))
+    interior = 0.5 * (lo_all + hi_all)
+    return _finish_graph(n, keys, pairs[:, 0], pairs[:, 1], polys, interior, 0, 1)

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.json.  Runs ONLY in the build container, where the
+reference tree is mounted at /root/reference; the fixtures it writes are plain
+JSON data and are what travels to the GPU box.
+
+Inputs taken from the reference (data only):
+  * test_data/{test1,test2,test3,test_autogen1,test_autogen2,benchmark1..4}.py:
+    the numeric case content ``As, bs, n`` (module contract of
+    test_data/test1.py:26-33).  The modules are imported with a two-function
+    stand-in for the ``utils`` module they import (the real one needs pydrake,
+    which is not installed); nothing else of the reference is executed.
+  * benchmark_data/admm_solver_v3_benchmark{1..4}.pkl and
+    classic_solver_benchmark{1..4}.pkl: the result records written by the
+    reference's utils.py:197-233.  Read with tools/pkl_reader.py, which parses
+    the opcode stream as data and never unpickles.
+
+The edge list of each case is produced by this repo's own ``build_graph``
+(gcs_admm_amd/graph.py); the reference's records do not store it.
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from gcs_admm_amd.graph import convert_pt_to_polytope, build_graph  # noqa: E402
+from pkl_reader import load_data  # noqa: E402
+
+CASES = ["test1", "test2", "test3", "test_autogen1", "test_autogen2",
+         "benchmark1", "benchmark2", "benchmark3", "benchmark4"]
+
+
+def _key(k):
+    return k if isinstance(k, str) else int(k)
+
+
+def main():
+    stub = types.ModuleType("utils")
+    stub.convert_pt_to_polytope = convert_pt_to_polytope
+    stub.visualize_results = lambda *a, **k: None
+    sys.modules["utils"] = stub
+    sys.path.append(os.path.join(REF, "test_data"))
+    sys.dont_write_bytecode = True
+    for case in CASES:
+        mod = importlib.import_module(case)
+        As, bs, n = mod.As, mod.bs, int(mod.n)
+        keys = [_key(k) for k in As.keys()]
+        V, E, _, _ = build_graph(As, bs)
+        rec = {
+            "name": case, "n": n, "keys": keys,
+            "As": [np.asarray(As[k], float).tolist() for k in As.keys()],
+            "bs": [np.asarray(bs[k], float).tolist() for k in As.keys()],
+            "edges": [[_key(u), _key(w)] for u, w in E],
+            "N": int(getattr(mod, "N", 0)), "M": int(getattr(mod, "M", 0)),
+        }
+        pk = os.path.join(REF, "benchmark_data", f"admm_solver_v3_{case}.pkl")
+        if os.path.exists(pk):
+            d = load_data(pk)
+            # the record carries the case too: cross-check the module content
+            for k in As.keys():
+                assert np.array_equal(np.asarray(As[k], float), np.asarray(d["As"][k], float))
+                assert np.array_equal(np.asarray(bs[k], float), np.asarray(d["bs"][k], float))
+            rec["golden_v3"] = {
+                "iterations": int(d["iterations"]),
+                "solve_time": float(d["solve_time"]),
+                "cost": float(d["cost"]),
+                "rho_seq": np.asarray(d["rho_seq"], float).tolist(),
+                "pri_res_seq": np.asarray(d["pri_res_seq"], float).tolist(),
+                "dual_res_seq": np.asarray(d["dual_res_seq"], float).tolist(),
+                "x_v_sol": [np.asarray(d["x_v_sol"][k], float).tolist() for k in As.keys()],
+                "y_v_sol": [float(d["y_v_sol"][k]) for k in As.keys()],
+                "x_v_rounded": [np.asarray(d["x_v_rounded"][k], float).tolist() for k in As.keys()],
+                "y_v_rounded": [float(d["y_v_rounded"][k]) for k in As.keys()],
+            }
+            c = load_data(os.path.join(REF, "benchmark_data", f"classic_solver_{case}.pkl"))
+            rec["golden_classic"] = {"cost": float(c["cost"]), "solve_time": float(c["solve_time"])}
+        out = os.path.join(HERE, f"{case}.json")
+        with open(out, "w") as f:
+            json.dump(rec, f)
+        print(case, "V", len(keys), "E", len(E), "->", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()
