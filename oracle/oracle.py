@@ -1,0 +1,98 @@
+"""ctypes binding of the CPU oracle (oracle/gcs_oracle.c).  Test infrastructure:
+imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libgcs_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "gcs_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    return LIB
+
+
+class _Graph(C.Structure):
+    _fields_ = [("n", C.c_int), ("V", C.c_int), ("E", C.c_int),
+                ("edge_tail", C.c_void_p), ("edge_head", C.c_void_p),
+                ("inc_ptr", C.c_void_p), ("inc_edge", C.c_void_p), ("inc_out", C.c_void_p),
+                ("edge_inc_tail", C.c_void_p), ("edge_inc_head", C.c_void_p),
+                ("poly_ptr", C.c_void_p), ("poly_A", C.c_void_p), ("poly_b", C.c_void_p),
+                ("center", C.c_void_p), ("src", C.c_int), ("dst", C.c_int)]
+
+
+class _Inner(C.Structure):
+    _fields_ = [("eps_edge", C.c_double), ("ipm_tol", C.c_double), ("ipm_max_iter", C.c_int)]
+
+
+class _Admm(C.Structure):
+    _fields_ = [("rho", C.c_double), ("tau_incr", C.c_double), ("tau_decr", C.c_double), ("nu", C.c_double),
+                ("it_rho_limit", C.c_int), ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_it", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        _lib.oracle_compute_cost.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """One GCS instance on the CPU oracle.  State arrays are numpy float64 in the
+    shared layout: copy/mu [c, 2E], zedge [c, E], xv/zv [V, 2n], yv [V]."""
+
+    def __init__(self, g, ipm_tol=1e-11, ipm_max_iter=60, eps_edge=1e-4):
+        self.g = g
+        self._keep = [np.ascontiguousarray(a) for a in (
+            g.edge_tail, g.edge_head, g.inc_ptr, g.inc_edge, g.inc_out, g.edge_inc_tail, g.edge_inc_head,
+            g.poly_ptr, g.poly_A, g.poly_b, g.interior)]
+        k = self._keep
+        self.G = _Graph(g.n, g.num_vertices, g.num_edges, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]),
+                        _p(k[5]), _p(k[6]), _p(k[7]), _p(k[8]), _p(k[9]), _p(k[10]), g.src, g.dst)
+        self.inner = _Inner(eps_edge, ipm_tol, ipm_max_iter)
+        c, E, V, n = g.c, g.num_edges, g.num_vertices, g.n
+        self.zedge = np.zeros((c, E)); self.mu = np.zeros((c, 2 * E)); self.copy = np.zeros((c, 2 * E))
+        self.xv = np.zeros((V, 2 * n)); self.zv = np.zeros((V, 2 * n)); self.yv = np.zeros(V)
+        self.ipm_iters = C.c_long(0)
+
+    def vertex_step(self, rho=1.0, mu_scale=1.0, nthreads=0):
+        return lib().oracle_vertex_step(C.byref(self.G), _p(self.zedge), _p(self.mu), C.c_double(mu_scale),
+                                        C.c_double(rho), C.byref(self.inner), _p(self.copy), _p(self.xv),
+                                        _p(self.zv), _p(self.yv), C.byref(self.ipm_iters), nthreads)
+
+    def edge_step(self, mu_scale=1.0):
+        s = np.zeros(5)
+        lib().oracle_edge_step(C.byref(self.G), _p(self.copy), _p(self.zedge), _p(self.mu), C.c_double(mu_scale), _p(s))
+        return s
+
+    def run(self, max_it=1000, rho=1.0, eps_abs=1e-4, eps_rel=1e-3, tau=2.0, nu=10.0, it_rho_limit=100, nthreads=0):
+        ap = _Admm(rho, tau, tau, nu, it_rho_limit, eps_abs, eps_rel, max_it)
+        trace = np.zeros((max_it, 6)); status = C.c_int(0)
+        it = lib().oracle_admm_run(C.byref(self.G), C.byref(ap), C.byref(self.inner), _p(self.zedge), _p(self.mu),
+                                   _p(self.copy), _p(self.xv), _p(self.zv), _p(self.yv), _p(trace), C.byref(status),
+                                   C.byref(self.ipm_iters), nthreads)
+        k = min(it, max_it)
+        return dict(iterations=it, status=status.value, trace=trace[:k],
+                    rho_seq=np.concatenate([[rho], trace[:k, 0]]),
+                    pri_res_seq=np.concatenate([[0.0], trace[:k, 1]]),
+                    dual_res_seq=np.concatenate([[0.0], trace[:k, 2]]),
+                    inner_failures=int(trace[:k, 5].sum()), cost=self.cost())
+
+    def cost(self):
+        return lib().oracle_compute_cost(C.byref(self.G), _p(self.zv), _p(self.zedge), C.c_double(self.inner.eps_edge))
