@@ -1,0 +1,645 @@
+// gcsadmm.hip -- gfx950 kernels and C ABI (include/gcsadmm.h) of the ADMM iteration loop.
+//
+// Kernels (one HIP stream, launched back to back, no host round trip inside the loop):
+//   vertex_kernel<N,T>   x-update, generic vertices: one wavefront per workgroup, several vertices per
+//                        wavefront, program in vertex_program.h          (admm_solver_v3.py:352-540)
+//   special_kernel<N,T>  x-update of s, t (closed form) and of vertices no flow can cross
+//   edge_kernel<T>       z-update, dual update, five partial norms        (admm_solver_v3.py:543-614)
+//   control_kernel       deterministic final reduction, residuals, rho adaptation, stop test,
+//                        trace record                                      (admm_solver_v3.py:697-733)
+//   cost_kernel<T>       GCS_utils.py:184-211
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gcsadmm.h"
+#include "vertex_program.h"
+
+namespace {
+
+using namespace gcs;
+
+constexpr int EDGE_BLOCK = 256;
+constexpr int MAX_SPECIAL_DEG = 256;
+
+// -------------------------------------------------------------------------------------------------
+// vertex kernel
+// -------------------------------------------------------------------------------------------------
+template <int N> struct GpuExec {
+    Lane<N> &L;
+    int lane;
+    template <class F> __device__ __forceinline__ void each(F &&f)
+    {
+        f(L, lane);
+        __syncthreads();
+    }
+    template <class P> __device__ __forceinline__ bool all(P &&p) { return __all(p(L) ? 1 : 0) != 0; }
+    __device__ __forceinline__ void count(int *c, int fails, int iters)
+    {
+        if (fails) atomicAdd(&c[0], fails);
+        atomicAdd(&c[1], iters);
+    }
+};
+
+template <int N, class T>
+__global__ __launch_bounds__(WAVE) void vertex_kernel(VertexArgs<T> a, const gcsadmm_control_block *cb)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (cb->status != GCSADMM_RUNNING) return;
+    const double rho = cb->rho, mu_scale = cb->mu_scale;
+    WaveShared S;
+    S.MM = a.MM;
+    S.lamA = smem;
+    S.lamB = S.lamA + 2 * a.MM * WAVE;
+    S.stage = S.lamB + 2 * a.MM * WAVE;
+    S.slots = S.stage + RED_CHUNK * WAVE;
+    Lane<N> L;
+    GpuExec<N> ex{L, (int)threadIdx.x};
+    run_vertex_program<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
+}
+
+// -------------------------------------------------------------------------------------------------
+// special vertices: s / t are points (utils.py:12-28, boxes of half-width 1e-6) -> the sub-problem
+// collapses to a separable quadratic over the simplex of the live side; a vertex with no incoming or
+// no outgoing edge carries no flow.  One thread per vertex.
+// -------------------------------------------------------------------------------------------------
+template <class T> struct SpecialArgs {
+    int count;
+    const int *vtx;     // vertex ids
+    const int *kind;    // 1 = source, 2 = target, 0 = no-flow
+    const int *inc_ptr, *deg_in, *inc_edge;
+    const double *center;
+    int E, NI;
+    const T *zedge, *mu;
+    T *copy;
+    double *xv, *zv, *yv;
+    double eps_edge;
+};
+
+template <int N, class T>
+__global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.count) return;
+    const double rho = cb->rho, mu_scale = cb->mu_scale;
+    const int v = a.vtx[i], kind = a.kind[i];
+    const int lo = a.inc_ptr[v], d = a.inc_ptr[v + 1] - lo, d_in = a.deg_in[v];
+    double cen[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) cen[k] = a.center[(size_t)v * N + k];
+    auto target = [&](int w, int k) -> double {
+        const int inc = lo + k, e = a.inc_edge[inc];
+        return (double)a.zedge[(size_t)w * a.E + e] - mu_scale * (double)a.mu[(size_t)w * a.NI + inc];
+    };
+    const bool is_src = kind == 1, is_dst = kind == 2;
+    const int live_lo = is_src ? d_in : 0, live_hi = is_src ? d : (is_dst ? d_in : 0);
+    const int na = live_hi - live_lo;
+    double vals[MAX_SPECIAL_DEG];
+    double tau = 0.0;
+    if (na > 0) {
+        double pp = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) pp += cen[k] * cen[k];
+        const double aq = is_src ? 2 * pp + 1 : pp + 1;
+        for (int e = live_lo; e < live_hi; ++e) {
+            double cc = target(2 * N, e);
+#pragma unroll
+            for (int k = 0; k < N; ++k) cc += cen[k] * (is_src ? target(k, e) + target(N + k, e) : target(N + k, e));
+            vals[e - live_lo] = (cc - a.eps_edge / rho) / aq;
+        }
+        // threshold of the Euclidean projection onto the simplex: sort descending (insertion), scan
+        double u[MAX_SPECIAL_DEG];
+        for (int q = 0; q < na; ++q) u[q] = vals[q];
+        for (int q = 1; q < na; ++q) {
+            const double x = u[q];
+            int j = q - 1;
+            while (j >= 0 && u[j] < x) { u[j + 1] = u[j]; --j; }
+            u[j + 1] = x;
+        }
+        double css = 0;
+        for (int k = 0; k < na; ++k) {
+            css += u[k];
+            if (u[k] * (k + 1) > css - 1.0) tau = (css - 1.0) / (k + 1);
+        }
+    }
+    for (int e = 0; e < d; ++e) {
+        const bool live = e >= live_lo && e < live_hi;
+        double ye = 0.0;
+        if (live) { ye = vals[e - live_lo] - tau; ye = ye > 0 ? ye : 0.0; }
+        const bool outgoing = e >= d_in;
+        const int inc = lo + e;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double yc = (kind != 0) ? ye * cen[k] : 0.0;
+            a.copy[(size_t)k * a.NI + inc] = (T)(outgoing ? yc : target(k, e));
+            a.copy[(size_t)(N + k) * a.NI + inc] = (T)yc;
+        }
+        a.copy[(size_t)(2 * N) * a.NI + inc] = (T)ye;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a.xv[(size_t)v * 2 * N + k] = a.xv[(size_t)v * 2 * N + N + k] = cen[k];
+        a.zv[(size_t)v * 2 * N + k] = a.zv[(size_t)v * 2 * N + N + k] = (kind != 0) ? cen[k] : 0.0;
+    }
+    a.yv[v] = (kind != 0) ? 1.0 : 0.0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// edge kernel: one thread per directed edge, all c coupled words
+// -------------------------------------------------------------------------------------------------
+template <class T> struct EdgeArgs {
+    int E, NI, c;
+    const int *edge_inc_tail, *edge_inc_head;
+    const uint8_t *inc_counted, *edge_counted;   // may be null
+    const T *copy;
+    T *zedge, *mu;
+    double *partials;    // [gridDim.x][5]
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <class T>
+__global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, const gcsadmm_control_block *cb)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    const double mu_scale = cb->mu_scale;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.E; e += gridDim.x * blockDim.x) {
+        const int it = a.edge_inc_tail[e], ih = a.edge_inc_head[e];
+        const double we = a.edge_counted ? (double)a.edge_counted[e] : 1.0;
+        const double wt = a.inc_counted ? (double)a.inc_counted[it] : 1.0;
+        const double wh = a.inc_counted ? (double)a.inc_counted[ih] : 1.0;
+        for (int w = 0; w < a.c; ++w) {
+            const double cu = (double)a.copy[(size_t)w * a.NI + it], cw = (double)a.copy[(size_t)w * a.NI + ih];
+            const double zo = (double)a.zedge[(size_t)w * a.E + e];
+            const T zn_t = (T)(0.5 * (cu + cw));
+            const double zn = (double)zn_t;
+            const double ru = cu - zn, rw = cw - zn;
+            const T mu_u_t = (T)(mu_scale * (double)a.mu[(size_t)w * a.NI + it] + ru);
+            const T mu_w_t = (T)(mu_scale * (double)a.mu[(size_t)w * a.NI + ih] + rw);
+            a.mu[(size_t)w * a.NI + it] = mu_u_t;
+            a.mu[(size_t)w * a.NI + ih] = mu_w_t;
+            a.zedge[(size_t)w * a.E + e] = zn_t;
+            const double mu_u = (double)mu_u_t, mu_w = (double)mu_w_t;
+            s[0] += wt * ru * ru + wh * rw * rw;
+            s[1] += we * (zn - zo) * (zn - zo);
+            s[2] += wt * cu * cu + wh * cw * cw;
+            s[3] += we * zn * zn;
+            s[4] += wt * mu_u * mu_u + wh * mu_w * mu_w;
+        }
+    }
+    __shared__ double red[EDGE_BLOCK / WAVE][5];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double t = wave_sum(s[k]);
+        if (lane == 0) red[wv][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double t = 0;
+        for (int q = 0; q < EDGE_BLOCK / WAVE; ++q) t += red[q][threadIdx.x];
+        a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
+    }
+}
+
+// fixed-order reduction of the per-workgroup partials -> sums[5]
+__global__ __launch_bounds__(256) void finalize_kernel(const double *partials, int nblocks, double *sums,
+                                                      const gcsadmm_control_block *cb)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    __shared__ double red[256][5];
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int k = 0; k < 5; ++k) s[k] += partials[(size_t)b * 5 + k];
+    for (int k = 0; k < 5; ++k) red[threadIdx.x][k] = s[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 5; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) sums[threadIdx.x] = red[0][threadIdx.x];
+}
+
+struct ControlParams {
+    double tau_incr, tau_decr, nu, eps_abs, eps_rel, nx, nmu;
+    int it_rho_limit, max_it;
+};
+
+// admm_solver_v3.py:697-733 on the five (globally reduced) sums
+__global__ void control_kernel(gcsadmm_control_block *cb, const double *sums, ControlParams p, int *counters, double *trace)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (cb->status != GCSADMM_RUNNING) return;
+    double s[5];
+    for (int k = 0; k < 5; ++k) { s[k] = sums[k]; cb->sums[k] = s[k]; }
+    const int it = cb->it;
+    double rho = cb->rho;
+    const int fails = counters[0], iters = counters[1];
+    counters[0] = 0; counters[1] = 0;
+    cb->inner_failures = fails; cb->inner_iters = iters;
+    const double tot = s[0] + s[1] + s[2] + s[3] + s[4];
+    if (!(tot == tot) || fabs(tot) > 1.7e308) {   // non-finite iterate: admm_solver_v3.py:662-664, 679-681
+        cb->status = GCSADMM_DIVERGED;
+        return;
+    }
+    const double pri = sqrt(s[0]), dual = rho * sqrt(2.0 * s[1]);
+    double mu_scale = 1.0;
+    if (pri >= p.nu * dual && it < p.it_rho_limit) { rho *= p.tau_incr; mu_scale = 1.0 / p.tau_incr; }
+    else if (dual >= p.nu * pri && it < p.it_rho_limit) { rho *= 1.0 / p.tau_decr; mu_scale = p.tau_incr; }
+    const double eps_pri = sqrt(p.nx) * p.eps_abs + p.eps_rel * fmax(sqrt(s[2]), sqrt(2.0 * s[3]));
+    const double eps_dual = sqrt(p.nmu) * p.eps_abs + p.eps_rel * mu_scale * sqrt(s[4]);
+    cb->rho = rho; cb->mu_scale = mu_scale;
+    cb->pri = pri; cb->dual = dual; cb->eps_pri = eps_pri; cb->eps_dual = eps_dual;
+    if (trace) {
+        double *tr = trace + (size_t)(it - 1) * 6;
+        tr[0] = rho; tr[1] = pri; tr[2] = dual; tr[3] = eps_pri; tr[4] = eps_dual; tr[5] = (double)fails;
+    }
+    if (pri < eps_pri && dual < eps_dual) { cb->status = GCSADMM_CONVERGED; return; }
+    cb->it = it + 1;
+    if (it + 1 > p.max_it) cb->status = GCSADMM_MAX_IT;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void cost_kernel(int V, int E, int n, const double *zv, const T *zedge,
+                                                   const uint8_t *edge_counted, double eps_edge, double *cost)
+{
+    // single workgroup, fixed order: this runs once after the loop
+    __shared__ double red[256];
+    double s = 0;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        double q = 0;
+        for (int k = 0; k < n; ++k) { const double dlt = zv[(size_t)v * 2 * n + k] - zv[(size_t)v * 2 * n + n + k]; q += dlt * dlt; }
+        s += sqrt(q);
+    }
+    for (int e = threadIdx.x; e < E; e += 256)
+        s += eps_edge * (edge_counted ? (double)edge_counted[e] : 1.0) * (double)zedge[(size_t)(2 * n) * E + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cost[0] = red[0];
+}
+
+
+} // namespace
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct gcsadmm_handle_s {
+    int n = 0, V = 0, E = 0, NI = 0, NI_owned = 0, c = 0, MM = 0, dtype = 0, device = 0;
+    int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
+    double nx = 0, nmu = 0;
+    gcsadmm_params params{};
+    bool params_set = false;
+    // device buffers
+    int *d_inc_ptr = nullptr, *d_deg_in = nullptr, *d_inc_edge = nullptr, *d_poly_ptr = nullptr;
+    int *d_edge_inc_tail = nullptr, *d_edge_inc_head = nullptr;
+    int *d_wave_slot_ptr = nullptr, *d_wave_vtx = nullptr, *d_special_vtx = nullptr, *d_special_kind = nullptr;
+    double *d_poly_A = nullptr, *d_poly_bc = nullptr, *d_center = nullptr;
+    uint8_t *d_inc_counted = nullptr, *d_edge_counted = nullptr;
+    gcsadmm_control_block *d_cb = nullptr;
+    int *d_counters = nullptr;
+    double *d_partials = nullptr, *d_sums = nullptr;
+    std::vector<hipEvent_t> events;
+    std::string err;
+};
+
+static std::string g_create_error;
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return GCSADMM_ERR_HIP;                                                                  \
+        }                                                                                            \
+    } while (0)
+
+template <class U> static hipError_t upload(U **dst, const U *src, size_t count)
+{
+    *dst = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)dst, count * sizeof(U));
+    if (e != hipSuccess) return e;
+    if (src) return hipMemcpy(*dst, src, count * sizeof(U), hipMemcpyHostToDevice);
+    return hipMemset(*dst, 0, count * sizeof(U));
+}
+
+template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
+{
+    if (h->n_waves > 0) {
+        VertexArgs<T> a;
+        a.n_waves = h->n_waves; a.wave_slot_ptr = h->d_wave_slot_ptr; a.wave_vtx = h->d_wave_vtx;
+        a.inc_ptr = h->d_inc_ptr; a.deg_in = h->d_deg_in; a.inc_edge = h->d_inc_edge; a.poly_ptr = h->d_poly_ptr;
+        a.poly_A = h->d_poly_A; a.poly_bc = h->d_poly_bc; a.center = h->d_center;
+        a.E = h->E; a.NI = h->NI; a.MM = h->MM;
+        a.zedge = (const T *)st->zedge; a.mu = (const T *)st->mu; a.copy = (T *)st->copy;
+        a.xv = st->xv; a.zv = st->zv; a.yv = st->yv; a.counters = h->d_counters;
+        a.eps_edge = h->params.eps_edge; a.ipm_tol = h->params.ipm_tol; a.ipm_max_iter = h->params.ipm_max_iter;
+        hipLaunchKernelGGL((vertex_kernel<2, T>), dim3(h->n_waves), dim3(WAVE), h->lds_bytes, s, a, h->d_cb);
+    }
+    if (h->n_special > 0) {
+        SpecialArgs<T> a;
+        a.count = h->n_special; a.vtx = h->d_special_vtx; a.kind = h->d_special_kind;
+        a.inc_ptr = h->d_inc_ptr; a.deg_in = h->d_deg_in; a.inc_edge = h->d_inc_edge; a.center = h->d_center;
+        a.E = h->E; a.NI = h->NI; a.zedge = (const T *)st->zedge; a.mu = (const T *)st->mu; a.copy = (T *)st->copy;
+        a.xv = st->xv; a.zv = st->zv; a.yv = st->yv; a.eps_edge = h->params.eps_edge;
+        hipLaunchKernelGGL((special_kernel<2, T>), dim3((h->n_special + 63) / 64), dim3(64), 0, s, a, h->d_cb);
+    }
+    HIPCHK(h, hipGetLastError());
+    return GCSADMM_OK;
+}
+
+template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcsadmm_state *st, double *sums, hipStream_t s)
+{
+    EdgeArgs<T> a;
+    a.E = h->E; a.NI = h->NI; a.c = h->c; a.edge_inc_tail = h->d_edge_inc_tail; a.edge_inc_head = h->d_edge_inc_head;
+    a.inc_counted = h->d_inc_counted; a.edge_counted = h->d_edge_counted;
+    a.copy = (const T *)st->copy; a.zedge = (T *)st->zedge; a.mu = (T *)st->mu; a.partials = h->d_partials;
+    hipLaunchKernelGGL((edge_kernel<T>), dim3(h->edge_blocks), dim3(EDGE_BLOCK), 0, s, a, h->d_cb);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, h->d_partials, h->edge_blocks, sums, h->d_cb);
+    HIPCHK(h, hipGetLastError());
+    return GCSADMM_OK;
+}
+
+static bool state_ok(gcsadmm_handle h, const gcsadmm_state *st)
+{
+    if (!h || !st || !st->copy || !st->mu || !st->zedge || !st->xv || !st->zv || !st->yv) { if (h) h->err = "null state pointer"; return false; }
+    if (!h->params_set) { h->err = "gcsadmm_reset has not been called"; return false; }
+    return true;
+}
+
+extern "C" {
+
+const char *gcsadmm_last_error(gcsadmm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void gcsadmm_destroy(gcsadmm_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void *ptrs[] = {h->d_inc_ptr, h->d_deg_in, h->d_inc_edge, h->d_poly_ptr, h->d_edge_inc_tail, h->d_edge_inc_head,
+                    h->d_wave_slot_ptr, h->d_wave_vtx, h->d_special_vtx, h->d_special_kind, h->d_poly_A, h->d_poly_bc,
+                    h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto ev : h->events) (void)hipEventDestroy(ev);
+    delete h;
+}
+
+gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
+{
+    if (out) *out = nullptr;
+    auto fail = [&](gcsadmm_status st, const std::string &msg) { g_create_error = msg; return st; };
+    if (!g || !out) return fail(GCSADMM_ERR_BAD_ARG, "null descriptor or output pointer");
+    if (g->n != 2) return fail(GCSADMM_ERR_UNSUPPORTED, "only n = 2 is implemented by the current vertex kernel");
+    if (g->num_vertices < 0 || g->num_edges < 0) return fail(GCSADMM_ERR_BAD_ARG, "negative size");
+    if (!g->inc_ptr || !g->poly_ptr || (g->num_edges > 0 && (!g->inc_edge || !g->inc_out || !g->edge_inc_tail || !g->edge_inc_head)) ||
+        (g->num_vertices > 0 && (!g->poly_A || !g->poly_b || !g->center)))
+        return fail(GCSADMM_ERR_BAD_ARG, "null graph array");
+    if (g->state_dtype != GCSADMM_F64 && g->state_dtype != GCSADMM_F32) return fail(GCSADMM_ERR_BAD_ARG, "bad state_dtype");
+    const int V = g->num_vertices, E = g->num_edges, n = g->n;
+    const int NIo = g->inc_ptr[V];
+    if (g->inc_ptr[0] != 0 || NIo < 0 || g->num_incidences < NIo) return fail(GCSADMM_ERR_BAD_ARG, "inconsistent incidence CSR");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GCSADMM_ERR_NO_DEVICE, "no HIP device");
+    if (g->device < 0 || g->device >= ndev) return fail(GCSADMM_ERR_BAD_ARG, "device ordinal out of range");
+
+    // validate CSR, derive deg_in, facet maximum
+    std::vector<int> deg_in(V, 0);
+    int MM = 1;
+    for (int v = 0; v < V; ++v) {
+        const int lo = g->inc_ptr[v], hi = g->inc_ptr[v + 1];
+        if (hi < lo) return fail(GCSADMM_ERR_BAD_ARG, "inc_ptr not monotone");
+        bool seen_out = false;
+        for (int k = lo; k < hi; ++k) {
+            if (g->inc_edge[k] < 0 || g->inc_edge[k] >= E) return fail(GCSADMM_ERR_BAD_ARG, "inc_edge out of range");
+            if (g->inc_out[k]) seen_out = true;
+            else { if (seen_out) return fail(GCSADMM_ERR_BAD_ARG, "incoming incidences must precede outgoing ones"); deg_in[v]++; }
+        }
+        const int m = g->poly_ptr[v + 1] - g->poly_ptr[v];
+        if (m < n + 1) return fail(GCSADMM_ERR_BAD_ARG, "polytope with fewer than n+1 facets cannot be bounded");
+        MM = std::max(MM, m);
+    }
+    for (int e = 0; e < E; ++e)
+        if (g->edge_inc_tail[e] < 0 || g->edge_inc_tail[e] >= g->num_incidences || g->edge_inc_head[e] < 0 ||
+            g->edge_inc_head[e] >= g->num_incidences)
+            return fail(GCSADMM_ERR_BAD_ARG, "edge incidence slot out of range");
+
+    // centred right-hand sides b - A c
+    const int MT = g->poly_ptr[V];
+    std::vector<double> bc(MT > 0 ? MT : 1);
+    for (int v = 0; v < V; ++v)
+        for (int j = g->poly_ptr[v]; j < g->poly_ptr[v + 1]; ++j) {
+            double s = g->poly_b[j];
+            for (int k = 0; k < n; ++k) s -= g->poly_A[(size_t)j * n + k] * g->center[(size_t)v * n + k];
+            bc[j] = s;
+            if (v != g->src && v != g->dst && !(s > 0.0)) return fail(GCSADMM_ERR_BAD_ARG, "center is not strictly inside its polytope");
+        }
+
+    // classify vertices and pack the generic ones into wavefronts: d+1 lanes each
+    std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx;
+    int slots_cap = MAX_SLOTS;
+    while (slots_cap > 1 && (size_t)lds_doubles(n, MM, slots_cap) * 8 > 160 * 1024) --slots_cap;
+    if ((size_t)lds_doubles(n, MM, slots_cap) * 8 > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
+    int lanes = 0, slots = 0, max_slots_used = 0;
+    for (int v = 0; v < V; ++v) {
+        const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
+        if (v == g->src || v == g->dst || din == 0 || dout == 0) {
+            if (d > MAX_SPECIAL_DEG) return fail(GCSADMM_ERR_UNSUPPORTED, "terminal vertex degree above 256");
+            special_vtx.push_back(v);
+            special_kind.push_back(v == g->src ? 1 : (v == g->dst ? 2 : 0));
+            continue;
+        }
+        if (d + 1 > WAVE) return fail(GCSADMM_ERR_UNSUPPORTED, "vertex degree above 63 is not supported by the vertex kernel");
+        if (lanes + d + 1 > WAVE || slots + 1 > slots_cap) {
+            wave_slot_ptr.push_back((int)wave_vtx.size());
+            lanes = 0; slots = 0;
+        }
+        wave_vtx.push_back(v);
+        lanes += d + 1; slots += 1;
+        max_slots_used = std::max(max_slots_used, slots);
+    }
+    if ((int)wave_vtx.size() > wave_slot_ptr.back()) wave_slot_ptr.push_back((int)wave_vtx.size());
+    const int n_waves = (int)wave_slot_ptr.size() - 1;
+
+    auto *h = new (std::nothrow) gcsadmm_handle_s;
+    if (!h) return fail(GCSADMM_ERR_HIP, "out of host memory");
+    h->n = n; h->V = V; h->E = E; h->NI = g->num_incidences; h->NI_owned = NIo; h->c = 2 * n + 1; h->MM = MM;
+    h->dtype = g->state_dtype; h->device = g->device;
+    h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
+    h->slots_cap = std::max(1, max_slots_used);
+    h->lds_bytes = lds_doubles(n, MM, h->slots_cap) * 8;
+    h->nx = g->nx_global > 0 ? g->nx_global : (4.0 * n + 1) * (V + 2.0 * E);
+    h->nmu = g->nmu_global > 0 ? g->nmu_global : (4.0 * n + 2) * E;
+    h->edge_blocks = std::max(1, std::min((E + EDGE_BLOCK - 1) / EDGE_BLOCK, 2048));
+    auto bail = [&](hipError_t e, const char *what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+        gcsadmm_destroy(h);
+        return GCSADMM_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(g->device)) != hipSuccess) return bail(e, "hipSetDevice");
+#define UP(dst, src, cnt) if ((e = upload(&h->dst, src, (size_t)(cnt))) != hipSuccess) return bail(e, "upload " #dst)
+    UP(d_inc_ptr, g->inc_ptr, V + 1);
+    UP(d_deg_in, deg_in.data(), V);
+    UP(d_inc_edge, g->inc_edge, NIo);
+    UP(d_poly_ptr, g->poly_ptr, V + 1);
+    UP(d_edge_inc_tail, g->edge_inc_tail, E);
+    UP(d_edge_inc_head, g->edge_inc_head, E);
+    UP(d_wave_slot_ptr, wave_slot_ptr.data(), wave_slot_ptr.size());
+    UP(d_wave_vtx, wave_vtx.data(), wave_vtx.size());
+    UP(d_special_vtx, special_vtx.data(), special_vtx.size());
+    UP(d_special_kind, special_kind.data(), special_kind.size());
+    UP(d_poly_A, g->poly_A, (size_t)MT * n);
+    UP(d_poly_bc, bc.data(), MT);
+    UP(d_center, g->center, (size_t)V * n);
+    if (g->inc_counted) UP(d_inc_counted, g->inc_counted, g->num_incidences);
+    if (g->edge_counted) UP(d_edge_counted, g->edge_counted, E);
+    UP(d_cb, (const gcsadmm_control_block *)nullptr, 1);
+    UP(d_counters, (const int *)nullptr, 2);
+    UP(d_partials, (const double *)nullptr, (size_t)h->edge_blocks * 5);
+    UP(d_sums, (const double *)nullptr, 5);
+#undef UP
+    if (h->lds_bytes > 48 * 1024) {
+        if (h->dtype == GCSADMM_F64) e = hipFuncSetAttribute((const void *)vertex_kernel<2, double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+        else e = hipFuncSetAttribute((const void *)vertex_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+        if (e != hipSuccess) return bail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    *out = h;
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_reset(gcsadmm_handle h, const gcsadmm_params *p, void *stream)
+{
+    if (!h || !p) return GCSADMM_ERR_BAD_ARG;
+    if (!(p->rho > 0) || p->max_it < 1 || !(p->ipm_tol > 0) || p->ipm_max_iter < 1) { h->err = "bad parameter"; return GCSADMM_ERR_BAD_ARG; }
+    h->params = *p; h->params_set = true;
+    gcsadmm_control_block cb{};
+    cb.rho = p->rho; cb.mu_scale = 1.0; cb.it = 1; cb.status = GCSADMM_RUNNING;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_cb, &cb, sizeof(cb), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), (hipStream_t)stream));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));   // cb is a stack object
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_vertex_step(gcsadmm_handle h, const gcsadmm_state *st, void *stream)
+{
+    if (!state_ok(h, st)) return GCSADMM_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    return h->dtype == GCSADMM_F64 ? launch_vertex<double>(h, st, (hipStream_t)stream) : launch_vertex<float>(h, st, (hipStream_t)stream);
+}
+
+gcsadmm_status gcsadmm_edge_step(gcsadmm_handle h, const gcsadmm_state *st, double *sums_dev, void *stream)
+{
+    if (!state_ok(h, st) || !sums_dev) return GCSADMM_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    return h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, sums_dev, (hipStream_t)stream) : launch_edge<float>(h, st, sums_dev, (hipStream_t)stream);
+}
+
+gcsadmm_status gcsadmm_control(gcsadmm_handle h, const double *sums_dev, double *trace_dev, void *stream)
+{
+    if (!h || !sums_dev || !h->params_set) return GCSADMM_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const gcsadmm_params &p = h->params;
+    ControlParams cp{p.tau_incr, p.tau_decr, p.nu, p.eps_abs, p.eps_rel, h->nx, h->nmu, p.it_rho_limit, p.max_it};
+    hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d_cb, sums_dev, cp, h->d_counters, trace_dev);
+    HIPCHK(h, hipGetLastError());
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_run(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream)
+{
+    if (!state_ok(h, st) || k < 0) return GCSADMM_ERR_BAD_ARG;
+    for (int i = 0; i < k; ++i) {
+        gcsadmm_status s;
+        if ((s = gcsadmm_vertex_step(h, st, stream)) != GCSADMM_OK) return s;
+        if ((s = gcsadmm_edge_step(h, st, h->d_sums, stream)) != GCSADMM_OK) return s;
+        if ((s = gcsadmm_control(h, h->d_sums, trace_dev, stream)) != GCSADMM_OK) return s;
+    }
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream,
+                                 float *vertex_ms, int32_t *vertex_launches, float *edge_ms, int32_t *edge_launches)
+{
+    if (!state_ok(h, st) || k < 0 || !vertex_ms || !edge_ms || !vertex_launches || !edge_launches) return GCSADMM_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)4 * k;
+    while (h->events.size() < need) {
+        hipEvent_t ev;
+        HIPCHK(h, hipEventCreate(&ev));
+        h->events.push_back(ev);
+    }
+    for (int i = 0; i < k; ++i) {
+        gcsadmm_status r;
+        HIPCHK(h, hipEventRecord(h->events[4 * i + 0], s));
+        if ((r = gcsadmm_vertex_step(h, st, stream)) != GCSADMM_OK) return r;
+        HIPCHK(h, hipEventRecord(h->events[4 * i + 1], s));
+        HIPCHK(h, hipEventRecord(h->events[4 * i + 2], s));
+        if ((r = gcsadmm_edge_step(h, st, h->d_sums, stream)) != GCSADMM_OK) return r;
+        HIPCHK(h, hipEventRecord(h->events[4 * i + 3], s));
+        if ((r = gcsadmm_control(h, h->d_sums, trace_dev, stream)) != GCSADMM_OK) return r;
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    double vm = 0, em = 0;
+    for (int i = 0; i < k; ++i) {
+        float t = 0;
+        HIPCHK(h, hipEventElapsedTime(&t, h->events[4 * i + 0], h->events[4 * i + 1])); vm += t;
+        HIPCHK(h, hipEventElapsedTime(&t, h->events[4 * i + 2], h->events[4 * i + 3])); em += t;
+    }
+    *vertex_ms = (float)vm; *edge_ms = (float)em; *vertex_launches = k; *edge_launches = k;
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_read_control(gcsadmm_handle h, gcsadmm_control_block *out, void *stream)
+{
+    if (!h || !out) return GCSADMM_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_cb, sizeof(*out), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_cost(gcsadmm_handle h, const gcsadmm_state *st, double eps_edge, double *cost_dev, void *stream)
+{
+    if (!h || !st || !st->zv || !st->zedge || !cost_dev) return GCSADMM_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->dtype == GCSADMM_F64)
+        hipLaunchKernelGGL((cost_kernel<double>), dim3(1), dim3(256), 0, (hipStream_t)stream, h->V, h->E, h->n, st->zv,
+                           (const double *)st->zedge, h->d_edge_counted, eps_edge, cost_dev);
+    else
+        hipLaunchKernelGGL((cost_kernel<float>), dim3(1), dim3(256), 0, (hipStream_t)stream, h->V, h->E, h->n, st->zv,
+                           (const float *)st->zedge, h->d_edge_counted, eps_edge, cost_dev);
+    HIPCHK(h, hipGetLastError());
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_query(gcsadmm_handle h, int32_t *num_waves, int32_t *lds_bytes, int32_t *num_special)
+{
+    if (!h) return GCSADMM_ERR_BAD_ARG;
+    if (num_waves) *num_waves = h->n_waves;
+    if (lds_bytes) *lds_bytes = h->lds_bytes;
+    if (num_special) *num_special = h->n_special;
+    return GCSADMM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,237 @@
+"""Host side of the MI355X ADMM loop: thin ctypes binding of the C ABI
+(include/gcsadmm.h, built from gcs_admm_amd/csrc by ``build.py``) plus the
+driver that mirrors the reference's main loop (admm_solver_v3.py:621-733).
+
+Device buffers are PyTorch-ROCm tensors; the library only ever sees their
+``data_ptr()`` and the current HIP stream.  There is NO fallback: if the HIP
+library is missing or no GPU is visible this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .graph import GcsGraph
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgcsadmm.so")
+
+F64, F32 = 0, 1
+RUNNING, CONVERGED, MAX_IT, DIVERGED = -1, 0, 1, 2
+STATUS_NAME = {RUNNING: "running", CONVERGED: "converged", MAX_IT: "max_it", DIVERGED: "diverged"}
+
+EXPORTS = ["gcsadmm_create", "gcsadmm_destroy", "gcsadmm_last_error", "gcsadmm_reset", "gcsadmm_vertex_step",
+           "gcsadmm_edge_step", "gcsadmm_control", "gcsadmm_run", "gcsadmm_run_timed", "gcsadmm_read_control",
+           "gcsadmm_cost", "gcsadmm_query"]
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("num_vertices", C.c_int32), ("num_edges", C.c_int32), ("num_incidences", C.c_int32),
+                ("inc_ptr", C.c_void_p), ("inc_edge", C.c_void_p), ("inc_out", C.c_void_p),
+                ("edge_inc_tail", C.c_void_p), ("edge_inc_head", C.c_void_p),
+                ("poly_ptr", C.c_void_p), ("poly_A", C.c_void_p), ("poly_b", C.c_void_p), ("center", C.c_void_p),
+                ("src", C.c_int32), ("dst", C.c_int32), ("state_dtype", C.c_int32), ("device", C.c_int32),
+                ("inc_counted", C.c_void_p), ("edge_counted", C.c_void_p),
+                ("nx_global", C.c_double), ("nmu_global", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("rho", C.c_double), ("tau_incr", C.c_double), ("tau_decr", C.c_double), ("nu", C.c_double),
+                ("it_rho_limit", C.c_int32), ("max_it", C.c_int32), ("eps_abs", C.c_double), ("eps_rel", C.c_double),
+                ("eps_edge", C.c_double), ("ipm_tol", C.c_double), ("ipm_max_iter", C.c_int32), ("reserved", C.c_int32)]
+
+
+class State(C.Structure):
+    _fields_ = [("copy", C.c_void_p), ("mu", C.c_void_p), ("zedge", C.c_void_p),
+                ("xv", C.c_void_p), ("zv", C.c_void_p), ("yv", C.c_void_p)]
+
+
+class ControlBlock(C.Structure):
+    _fields_ = [("rho", C.c_double), ("mu_scale", C.c_double), ("sums", C.c_double * 5),
+                ("pri", C.c_double), ("dual", C.c_double), ("eps_pri", C.c_double), ("eps_dual", C.c_double),
+                ("it", C.c_int32), ("status", C.c_int32), ("inner_failures", C.c_int32), ("inner_iters", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m gcs_admm_amd.build` (hipcc, gfx950). "
+                               "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.gcsadmm_last_error.restype = C.c_char_p
+        lib.gcsadmm_last_error.argtypes = [C.c_void_p]
+        lib.gcsadmm_destroy.restype = None
+        lib.gcsadmm_destroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class GcsAdmmError(RuntimeError):
+    pass
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceSolver:
+    """One GCS instance (or one vertex partition of it) resident on one MI355X.
+
+    ``graph`` is the integer/CSR description (gcs_admm_amd.graph.GcsGraph).  For
+    a partition, ``num_incidences`` > ``inc_ptr[-1]`` adds ghost copy slots and
+    ``inc_counted`` / ``edge_counted`` implement the ownership rule of the
+    global norms.
+    """
+
+    def __init__(self, graph: GcsGraph, state_dtype: str = "f64", device: Optional[int] = None,
+                 num_incidences: Optional[int] = None, inc_counted=None, edge_counted=None,
+                 nx_global: float = 0.0, nmu_global: float = 0.0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the ADMM loop only runs on the GPU (no CPU fallback)")
+        self.torch = torch
+        self.lib = load_library()
+        self.g = graph
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.dtype_code = {"f64": F64, "f32": F32}[state_dtype]
+        self.tdtype = torch.float64 if state_dtype == "f64" else torch.float32
+        g = graph
+        ni_owned = int(g.inc_ptr[-1])
+        self.NI = int(num_incidences) if num_incidences is not None else ni_owned
+        self._keep = [np.ascontiguousarray(a) for a in (
+            g.inc_ptr.astype(np.int32), g.inc_edge.astype(np.int32), g.inc_out.astype(np.int32),
+            g.edge_inc_tail.astype(np.int32), g.edge_inc_head.astype(np.int32), g.poly_ptr.astype(np.int32),
+            g.poly_A.astype(np.float64), g.poly_b.astype(np.float64), g.interior.astype(np.float64))]
+        k = self._keep
+        ic = np.ascontiguousarray(inc_counted, dtype=np.uint8) if inc_counted is not None else None
+        ec = np.ascontiguousarray(edge_counted, dtype=np.uint8) if edge_counted is not None else None
+        self._keep += [ic, ec]
+        desc = GraphDesc(g.n, g.num_vertices, g.num_edges, self.NI, _np_ptr(k[0]), _np_ptr(k[1]), _np_ptr(k[2]),
+                         _np_ptr(k[3]), _np_ptr(k[4]), _np_ptr(k[5]), _np_ptr(k[6]), _np_ptr(k[7]), _np_ptr(k[8]),
+                         g.src, g.dst, self.dtype_code, self.device_index,
+                         _np_ptr(ic) if ic is not None else None, _np_ptr(ec) if ec is not None else None,
+                         float(nx_global), float(nmu_global))
+        h = C.c_void_p()
+        st = self.lib.gcsadmm_create(C.byref(desc), C.byref(h))
+        if st != 0:
+            raise GcsAdmmError(f"gcsadmm_create failed ({st}): {self.lib.gcsadmm_last_error(None).decode()}")
+        self.h = h
+        c, E, V, n = g.c, g.num_edges, g.num_vertices, g.n
+        z = lambda *s, dt=self.tdtype: torch.zeros(*s, dtype=dt, device=self.device)
+        self.copy, self.mu, self.zedge = z(c, self.NI), z(c, self.NI), z(c, E)
+        self.xv, self.zv, self.yv = z(V, 2 * n, dt=torch.float64), z(V, 2 * n, dt=torch.float64), z(V, dt=torch.float64)
+        self.sums = z(5, dt=torch.float64)
+        self._cost = z(1, dt=torch.float64)
+        self.state = State(self.copy.data_ptr(), self.mu.data_ptr(), self.zedge.data_ptr(),
+                           self.xv.data_ptr(), self.zv.data_ptr(), self.yv.data_ptr())
+        self.params = None
+        self.trace = None
+
+    # ------------------------------------------------------------------
+    def _check(self, st, what):
+        if st != 0:
+            raise GcsAdmmError(f"{what} failed ({st}): {self.lib.gcsadmm_last_error(self.h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gcsadmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def reset(self, rho=1.0, tau_incr=2.0, tau_decr=2.0, nu=10.0, it_rho_limit=100, max_it=1000, eps_abs=1e-4,
+              eps_rel=1e-3, eps_edge=1e-4, ipm_tol=1e-9, ipm_max_iter=60, zero_state=True):
+        """Start a loop with the reference's literals as defaults (admm_solver_v3.py:621-651)."""
+        self.params = Params(rho, tau_incr, tau_decr, nu, it_rho_limit, max_it, eps_abs, eps_rel, eps_edge,
+                             ipm_tol, ipm_max_iter, 0)
+        if zero_state:
+            for t in (self.copy, self.mu, self.zedge, self.xv, self.zv, self.yv):
+                t.zero_()
+        self.trace = self.torch.zeros(max_it, 6, dtype=self.torch.float64, device=self.device)
+        with self.torch.cuda.device(self.device):
+            self._check(self.lib.gcsadmm_reset(self.h, C.byref(self.params), self._stream()), "gcsadmm_reset")
+
+    def vertex_step(self):
+        self._check(self.lib.gcsadmm_vertex_step(self.h, C.byref(self.state), self._stream()), "gcsadmm_vertex_step")
+
+    def edge_step(self):
+        self._check(self.lib.gcsadmm_edge_step(self.h, C.byref(self.state), C.c_void_p(self.sums.data_ptr()),
+                                               self._stream()), "gcsadmm_edge_step")
+        return self.sums
+
+    def control(self, sums=None):
+        s = self.sums if sums is None else sums
+        self._check(self.lib.gcsadmm_control(self.h, C.c_void_p(s.data_ptr()), C.c_void_p(self.trace.data_ptr()),
+                                             self._stream()), "gcsadmm_control")
+
+    def enqueue(self, k: int):
+        """k iterations back to back, no host synchronisation."""
+        self._check(self.lib.gcsadmm_run(self.h, C.byref(self.state), int(k), C.c_void_p(self.trace.data_ptr()),
+                                         self._stream()), "gcsadmm_run")
+
+    def enqueue_timed(self, k: int):
+        vm, em = C.c_float(0), C.c_float(0)
+        vl, el = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.gcsadmm_run_timed(self.h, C.byref(self.state), int(k), C.c_void_p(self.trace.data_ptr()),
+                                               self._stream(), C.byref(vm), C.byref(vl), C.byref(em), C.byref(el)),
+                    "gcsadmm_run_timed")
+        return dict(vertex_ms=vm.value, vertex_launches=vl.value, edge_ms=em.value, edge_launches=el.value)
+
+    def read_control(self) -> ControlBlock:
+        cb = ControlBlock()
+        self._check(self.lib.gcsadmm_read_control(self.h, C.byref(cb), self._stream()), "gcsadmm_read_control")
+        return cb
+
+    def query(self):
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.gcsadmm_query(self.h, C.byref(a), C.byref(b), C.byref(c)), "gcsadmm_query")
+        return dict(num_waves=a.value, lds_bytes=b.value, num_special=c.value)
+
+    def cost(self) -> float:
+        eps = self.params.eps_edge if self.params is not None else 1e-4
+        self._check(self.lib.gcsadmm_cost(self.h, C.byref(self.state), C.c_double(eps), C.c_void_p(self._cost.data_ptr()),
+                                          self._stream()), "gcsadmm_cost")
+        return float(self._cost.item())
+
+    # ------------------------------------------------------------------
+    def solve(self, chunk: int = 25, **params):
+        """Run the loop to its stop test (or max_it), polling the device control
+        block every ``chunk`` iterations; returns the reference's record fields
+        (utils.py:212-229 naming) plus solver statistics."""
+        self.reset(**params)
+        max_it = self.params.max_it
+        done = 0
+        while True:
+            k = min(chunk, max_it - done)
+            if k > 0:
+                self.enqueue(k)
+                done += k
+            cb = self.read_control()
+            if cb.status != RUNNING or done >= max_it:
+                break
+        it = cb.it
+        k = min(it, max_it)
+        tr = self.trace[:k].cpu().numpy()
+        return dict(iterations=int(it), status=STATUS_NAME[cb.status],
+                    rho_seq=np.concatenate([[self.params.rho], tr[:, 0]]),
+                    pri_res_seq=np.concatenate([[0.0], tr[:, 1]]),
+                    dual_res_seq=np.concatenate([[0.0], tr[:, 2]]),
+                    eps_pri_seq=tr[:, 3], eps_dual_seq=tr[:, 4],
+                    inner_failures=int(tr[:, 5].sum()), cost=self.cost())

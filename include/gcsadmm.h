@@ -1,0 +1,164 @@
+/*
+ * gcsadmm.h -- C ABI of the MI355X (gfx950) implementation of the per-iteration
+ * loop of the reference's "full vertex split" ADMM solver for shortest paths in
+ * graphs of convex sets.
+ *
+ * The reference (Python) has no FFI seam; the call sites this library replaces
+ * are, in /root/reference/admm_solver_v3.py:
+ *     :469-540  parallel_vertex_update()  -- SolveInParallel(progs, MOSEK) + scatter   -> gcsadmm_vertex_step
+ *     :543-587  parallel_edge_update()    -- per-edge average of the two vertex copies \
+ *     :590-594  dual_update()             -- mu += A x + B z - c                        > gcsadmm_edge_step
+ *     :597-614  residuals, eps_pri/dual   -- the five norms                            /
+ *     :655-733  the while loop            -- order, rho adaptation, stop test          -> gcsadmm_control / gcsadmm_run
+ * and GCS_utils.py:184-211 compute_cost -> gcsadmm_cost.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no exit(): every entry point returns a gcsadmm_status code;
+ *     gcsadmm_last_error() gives the text of the last failure on that handle.
+ *   - graph description pointers are HOST pointers (copied at create); state, trace and
+ *     scalar buffers are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm tensors).
+ *   - one handle <-> one device <-> one stream at a time; calls on a handle are not re-entrant.
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).  All entry points
+ *     that take a stream only enqueue work; they never synchronise.
+ *
+ * State layout (shared with the CPU oracle): for every directed edge e=(u,w) the
+ * coupled words are [ z_{e,u}[0:n], z_{e,w}[0:n], y_e ]  (c = 2n+1 words).
+ *   copy [c][NI]   vertex copies, incidence-major (word-major rows of NI = incidences)
+ *   mu   [c][NI]   scaled duals of the consensus rows, same indexing
+ *   zedge[c][E]    edge copies
+ *   xv [V][2n], zv [V][2n], yv [V]   per-vertex outputs of the last vertex step
+ * Element type of copy/mu/zedge is f64 or f32 (desc.state_dtype); xv/zv/yv are f64.
+ * All interior-point arithmetic is f64 regardless.
+ */
+#ifndef GCSADMM_H
+#define GCSADMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gcsadmm_status {
+    GCSADMM_OK = 0,
+    GCSADMM_ERR_BAD_ARG = 1,        /* null pointer, negative size, inconsistent CSR, unsupported n */
+    GCSADMM_ERR_UNSUPPORTED = 2,    /* degree or facet count above the kernel's limits */
+    GCSADMM_ERR_HIP = 3,            /* a HIP runtime call failed */
+    GCSADMM_ERR_NO_DEVICE = 4
+} gcsadmm_status;
+
+enum { GCSADMM_F64 = 0, GCSADMM_F32 = 1 };
+
+/* loop exit reasons written to gcsadmm_control_block.status */
+enum { GCSADMM_RUNNING = -1, GCSADMM_CONVERGED = 0, GCSADMM_MAX_IT = 1, GCSADMM_DIVERGED = 2 };
+
+typedef struct gcsadmm_graph_desc {
+    int32_t n;                       /* space dimension (2 supported by the current kernels) */
+    int32_t num_vertices;            /* vertices whose sub-problem this handle solves */
+    int32_t num_edges;               /* directed edges this handle updates */
+    int32_t num_incidences;          /* NI: columns of copy/mu; >= inc_ptr[num_vertices]; the surplus are
+                                        ghost slots filled by the caller (halo of a vertex partition) */
+    const int32_t *inc_ptr;          /* [V+1] CSR over vertices; incoming edges first, then outgoing */
+    const int32_t *inc_edge;         /* [inc_ptr[V]] directed edge id of each incidence */
+    const int32_t *inc_out;          /* [inc_ptr[V]] 1 if the vertex is the tail of that edge */
+    const int32_t *edge_inc_tail;    /* [E] incidence slot holding the tail's copy of edge e */
+    const int32_t *edge_inc_head;    /* [E] incidence slot holding the head's copy */
+    const int32_t *poly_ptr;         /* [V+1] CSR over facets */
+    const double *poly_A;            /* [poly_ptr[V]][n] facet normals, A x <= b */
+    const double *poly_b;            /* [poly_ptr[V]] */
+    const double *center;            /* [V][n] a strictly interior point of each polytope */
+    int32_t src, dst;                /* local vertex ids of 's' and 't' (-1 if not in this partition) */
+    int32_t state_dtype;             /* GCSADMM_F64 / GCSADMM_F32 */
+    int32_t device;                  /* HIP device ordinal */
+    const uint8_t *inc_counted;      /* [NI] or NULL(=all 1): this handle owns the copy (counts it in the norms) */
+    const uint8_t *edge_counted;     /* [E]  or NULL(=all 1): this handle counts the edge in the norms */
+    double nx_global, nmu_global;    /* lengths of the reference's x / mu vectors for eps_pri / eps_dual
+                                        (admm_solver_v3.py:605-614); 0 = derive from this handle's sizes */
+} gcsadmm_graph_desc;
+
+typedef struct gcsadmm_params {
+    double rho;          /* initial penalty (1)                     admm_solver_v3.py:621 */
+    double tau_incr;     /* 2                                        :641 */
+    double tau_decr;     /* 2                                        :642 */
+    double nu;           /* 10                                       :643 */
+    int32_t it_rho_limit;/* rho adapts while it < this (0.1*1000)   :644,703 */
+    int32_t max_it;      /* 1000                                     :651 */
+    double eps_abs;      /* 1e-4                                     :647 */
+    double eps_rel;      /* 1e-3                                     :648 */
+    double eps_edge;     /* 1e-4 edge activation penalty             :388 */
+    double ipm_tol;      /* barrier parameter at which a vertex solve stops (1e-9) */
+    int32_t ipm_max_iter;/* 60 */
+    int32_t reserved;
+} gcsadmm_params;
+
+typedef struct gcsadmm_state {
+    void *copy;   /* [c][NI] */
+    void *mu;     /* [c][NI] */
+    void *zedge;  /* [c][E]  */
+    double *xv;   /* [V][2n] */
+    double *zv;   /* [V][2n] */
+    double *yv;   /* [V]     */
+} gcsadmm_state;
+
+/* Loop state kept on the device so that iterations can be enqueued back to back
+ * without host round trips.  Lives in device memory owned by the handle;
+ * gcsadmm_read_control copies it out (synchronising the given stream). */
+typedef struct gcsadmm_control_block {
+    double rho;           /* penalty used by the next vertex step */
+    double mu_scale;      /* pending rescale of mu (rho change), applied lazily by the next steps */
+    double sums[5];       /* |r|^2, |dz|^2, |copy|^2, |zedge|^2, |mu|^2 of the last edge step */
+    double pri, dual, eps_pri, eps_dual;
+    int32_t it;           /* iteration counter as the reference reports it (starts at 1) */
+    int32_t status;       /* GCSADMM_RUNNING / CONVERGED / MAX_IT / DIVERGED */
+    int32_t inner_failures; /* vertex solves of the last step that hit ipm_max_iter */
+    int32_t inner_iters;    /* interior-point iterations of the last step, summed over vertices */
+} gcsadmm_control_block;
+
+typedef struct gcsadmm_handle_s *gcsadmm_handle;
+
+gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *desc, gcsadmm_handle *out);
+void gcsadmm_destroy(gcsadmm_handle h);
+const char *gcsadmm_last_error(gcsadmm_handle h);   /* h may be NULL: error of the last failed create */
+
+/* (Re)start the loop: control block := {rho, mu_scale 1, it 1, RUNNING}.  Does not touch the state. */
+gcsadmm_status gcsadmm_reset(gcsadmm_handle h, const gcsadmm_params *p, void *stream);
+
+/* x-update: one convex sub-problem per vertex, all vertices of the handle.  Reads zedge, mu and
+ * the control block's rho / mu_scale; writes copy (owned incidences only), xv, zv, yv. */
+gcsadmm_status gcsadmm_vertex_step(gcsadmm_handle h, const gcsadmm_state *st, void *stream);
+
+/* z-update + dual update + the five partial norms over this handle's edges.  Reads copy (all NI
+ * columns: ghost slots must have been filled), updates zedge and mu in place, applies and clears
+ * the pending mu rescale, writes sums[5] (f64, device) -- the caller all-reduces them across
+ * partitions before gcsadmm_control when the graph is partitioned. */
+gcsadmm_status gcsadmm_edge_step(gcsadmm_handle h, const gcsadmm_state *st, double *sums_dev, void *stream);
+
+/* residuals, rho adaptation, stop test, it += 1 (admm_solver_v3.py:697-733) from sums_dev[5];
+ * appends {rho, pri, dual, eps_pri, eps_dual, inner_failures} to trace_dev[(it-1)*6 ..] if non-NULL. */
+gcsadmm_status gcsadmm_control(gcsadmm_handle h, const double *sums_dev, double *trace_dev, void *stream);
+
+/* Enqueue up to k full iterations (vertex, edge, control) with no host synchronisation; once the
+ * stop test fires the remaining enqueued kernels exit immediately. */
+gcsadmm_status gcsadmm_run(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream);
+
+/* Copy the control block to the host (synchronises `stream`). */
+gcsadmm_status gcsadmm_read_control(gcsadmm_handle h, gcsadmm_control_block *out, void *stream);
+
+/* sum_v |z_v[:n] - z_v[n:]| + eps_edge * sum_e y_e over counted edges -> cost_dev[0] (f64, device). */
+gcsadmm_status gcsadmm_cost(gcsadmm_handle h, const gcsadmm_state *st, double eps_edge, double *cost_dev, void *stream);
+
+/* Kernel-side facts for benchmarking: number of vertex-kernel workgroups, LDS bytes per workgroup,
+ * and the last measured average duration (ms) of the vertex kernel between two events, see bench.py */
+gcsadmm_status gcsadmm_query(gcsadmm_handle h, int32_t *num_waves, int32_t *lds_bytes, int32_t *num_special);
+
+/* As gcsadmm_run, but every kernel launch is bracketed by HIP events recorded on `stream`; after the
+ * k iterations the call synchronises and returns the summed device time (ms) and launch count of the
+ * vertex-step kernel(s) and of the edge-step kernel.  For measurement (bench.py roofline). */
+gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev,
+                                 void *stream, float *vertex_ms, int32_t *vertex_launches,
+                                 float *edge_ms, int32_t *edge_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCSADMM_H */

@@ -1,0 +1,65 @@
+import numpy as np
+import pytest
+
+from conftest import BENCHMARKS, SMALL
+from gcs_admm_amd import graph as G
+from gcs_admm_amd.cases import load_fixture
+
+SIZES = {"test1": (3, 4), "test2": (4, 6), "test3": (5, 14), "test_autogen1": (10, 38), "test_autogen2": (12, 36),
+         "benchmark1": (6, 12), "benchmark2": (10, 28), "benchmark3": (22, 76), "benchmark4": (42, 94)}
+
+
+@pytest.mark.parametrize("name", SMALL + BENCHMARKS)
+def test_fixture_graph_sizes_and_csr(name):
+    case, g = load_fixture(name)
+    assert (g.num_vertices, g.num_edges) == SIZES[name]
+    assert g.keys[g.src] == "s" and g.keys[g.dst] == "t"
+    E = g.num_edges
+    # symmetric overlap graph: (u,w) in E <=> (w,u) in E
+    pairs = set(zip(g.edge_tail.tolist(), g.edge_head.tolist()))
+    assert all((w, u) in pairs for u, w in pairs)
+    # CSR: incoming first (edge order), then outgoing (edge order); slots are a permutation
+    assert sorted(np.concatenate([g.edge_inc_tail, g.edge_inc_head]).tolist()) == list(range(2 * E))
+    for v in range(g.num_vertices):
+        lo, hi = g.inc_ptr[v], g.inc_ptr[v + 1]
+        outs = g.inc_out[lo:hi]
+        assert np.all(np.diff(outs) >= 0)
+        ins_e, outs_e = g.inc_edge[lo:hi][outs == 0], g.inc_edge[lo:hi][outs == 1]
+        assert np.all(g.edge_head[ins_e] == v) and np.all(g.edge_tail[outs_e] == v)
+        assert np.all(np.diff(ins_e) > 0) and np.all(np.diff(outs_e) > 0)
+    assert g.nx == (4 * g.n + 1) * (g.num_vertices + 2 * E) and g.nmu == (4 * g.n + 2) * E
+    # interior points are strictly inside
+    for v in range(g.num_vertices):
+        A = g.poly_A[g.poly_ptr[v]:g.poly_ptr[v + 1]]; b = g.poly_b[g.poly_ptr[v]:g.poly_ptr[v + 1]]
+        assert np.all(A @ g.interior[v] < b)
+
+
+def test_build_graph_matches_fixture_edges():
+    """own overlap test (LP feasibility / interval test) reproduces the committed edge list"""
+    case, g = load_fixture("benchmark2")
+    keys = case["keys"]
+    As = {k: np.array(a, float) for k, a in zip(keys, case["As"])}
+    bs = {k: np.array(b, float) for k, b in zip(keys, case["bs"])}
+    V, E, I_in, I_out = G.build_graph(As, bs)
+    assert V == keys and [list(e) for e in E] == case["edges"]
+    assert all(e[1] == v for v in V for e in I_in[v]) and all(e[0] == v for v in V for e in I_out[v])
+
+
+def test_convert_pt_and_delta():
+    A, b = G.convert_pt_to_polytope(np.array([1.0, -2.0]))
+    assert A.shape == (4, 2) and np.allclose(b, [1 + 1e-6, -2 + 1e-6, -1 + 1e-6, 2 + 1e-6])
+    assert G.delta('s', 's') == 1 and G.delta('t', 't') == 1 and G.delta('s', 't') == 0 and G.delta(0, 0) == 0
+
+
+def test_lattice_generator():
+    g = G.lattice_boxes(20, 12, seed=0)
+    assert g.num_vertices == 20 * 12 + 2
+    deg = np.diff(g.inc_ptr)
+    # interior cells overlap exactly their 4 neighbours in rows j+-1: 8 incidences
+    interior = [2 + j * 20 + i for j in range(1, 11) for i in range(1, 19) if (i, j) not in ((0, 0), (19, 11))]
+    assert np.all(deg[interior] == 8)
+    assert deg[g.src] == 2 and deg[g.dst] == 2        # s, t sit in exactly one cell
+    pairs = set(zip(g.edge_tail.tolist(), g.edge_head.tolist()))
+    assert all((w, u) in pairs for u, w in pairs)
+    g2 = G.lattice_boxes(20, 12, seed=0)
+    assert np.array_equal(g.poly_b, g2.poly_b) and np.array_equal(g.edge_tail, g2.edge_tail)
