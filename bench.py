@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM iterations/sec of the MI355X loop on the configuration BASELINE.json quotes its
+metric on (benchmark4, f64, reference stop rule), one JSON line on stdout.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload benchmark4|s10k]
+
+A "step" is one full ADMM iteration (vertex step, edge step, control) on the resident state; K steps
+are enqueued back to back (no host round trip) between two synchronisation points.  The state is
+already in HBM when the timed region starts.  `roofline` prices the dominant kernel (vertex step)
+with the algorithmic bytes of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle
+(oracle/gcs_oracle.c, "port") on the same workload on the host cores of the GPU box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+REF_PUBLISHED_ITS = 465 / 37.87852382659912   # v3 / benchmark4, solver-time-only, hardware unknown
+
+
+def make_workload(name, rank=0, world=1):
+    from gcs_admm_amd.cases import load_fixture
+    from gcs_admm_amd.graph import lattice_boxes
+    if name == "benchmark4":
+        case, g = load_fixture("benchmark4")
+        return g, "f64", dict(case=case)
+    if name == "s10k":
+        return lattice_boxes(100, 100, seed=0), "f32", {}
+    raise SystemExit(f"unknown workload {name}")
+
+
+def time_loop(dev, steps, warmup, params):
+    import torch
+    dev.reset(**params)
+    dev.enqueue(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev.enqueue(steps)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="benchmark4")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl")
+    from gcs_admm_amd.solver import DeviceSolver
+
+    g, dtype, extra = make_workload(args.workload, rank, world)
+    dev = DeviceSolver(g, dtype, device=local)
+    # fixed-length timing window: the stop test is disabled (eps = 0) so that exactly K iterations run
+    params = dict(max_it=args.steps + args.warmup + 1, eps_abs=0.0, eps_rel=0.0)
+    if world > 1:
+        dist.barrier()
+    el = time_loop(dev, args.steps, args.warmup, params)
+    cb = dev.read_control()
+    assert cb.it == args.steps + args.warmup + 1, (cb.it, cb.status)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    its = args.steps / el * world     # N independent replicas of the workload
+
+    out = {"metric": "admm_iterations_per_sec", "value": its, "unit": "iterations/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": its / REF_PUBLISHED_ITS / world if args.workload == "benchmark4" else None,
+           "dtype": "f64", "data": "synthetic" if args.workload != "benchmark4" else "fixture of the reference's test_data/benchmark4.py",
+           "config": {"workload": args.workload, "V": g.num_vertices, "E": g.num_edges, "n": g.n,
+                      "state_dtype": dtype, "inner_arithmetic": "f64", "ipm_tol": 1e-9,
+                      "parallelism": f"{world} replica(s)"}}
+    if rank == 0:
+        # ---- roofline of the dominant kernel (vertex step), measured with HIP events on its stream ----
+        dev.reset(**params)
+        dev.enqueue(args.warmup)
+        tm = dev.enqueue_timed(min(args.steps, 200))
+        v_ms = tm["vertex_ms"] / max(tm["vertex_launches"], 1)
+        e_ms = tm["edge_ms"] / max(tm["edge_launches"], 1)
+        wb = 8 if dtype == "f64" else 4
+        alg_bytes = g.algorithmic_bytes_per_iteration(wb)
+        ach = alg_bytes / (v_ms * 1e-3) / 1e9
+        q = dev.query()
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "vertex_kernel<2>", "avg_launch_ms": v_ms,
+                           "algorithmic_bytes_per_launch": alg_bytes, "edge_step_avg_ms": e_ms,
+                           "waves": q["num_waves"], "lds_bytes_per_wave": q["lds_bytes"],
+                           "inner_iters_last_step_total": dev.read_control().inner_iters,
+                           "special_vertices": q["num_special"]}
+        # ---- matched convergence: the reference's own stop rule ----
+        if args.workload == "benchmark4":
+            res = dev.solve()
+            gold = extra["case"]["golden_v3"]
+            out["convergence"] = {"iterations_to_stop": res["iterations"], "reference_iterations": gold["iterations"],
+                                  "cost": res["cost"], "reference_cost": gold["cost"],
+                                  "classic_cost": extra["case"]["golden_classic"]["cost"]}
+            out["reference_published"] = {"its_per_sec": REF_PUBLISHED_ITS, "note": "465 it / 37.88 s solver-time-only, hardware unknown (BASELINE.md)"}
+        # ---- CPU baseline: the oracle on the host cores, bounded sample ----
+        if not args.no_cpu:
+            from oracle.oracle import Oracle
+            cores = os.cpu_count() or 1
+            o = Oracle(g, ipm_tol=1e-9)
+            o.run(max_it=3, eps_abs=0.0, eps_rel=0.0, nthreads=cores)     # warm-up, also faults the pages in
+            n_it = 300 if args.workload == "benchmark4" else 20
+            o = Oracle(g, ipm_tol=1e-9)
+            t0 = time.perf_counter()
+            o.run(max_it=n_it, eps_abs=0.0, eps_rel=0.0, nthreads=cores)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_it / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n_it} iterations of the same workload from the zero state (oracle/gcs_oracle.c, OpenMP over vertices)"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

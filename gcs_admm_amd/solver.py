@@ -65,6 +65,10 @@ def load_library() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -m gcs_admm_amd.build` (hipcc, gfx950). "
                                "There is no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP runtime (same SONAME as /opt/rocm's): it must be the one already
+        # loaded when libgcsadmm.so resolves libamdhip64, or the process ends up with two runtimes and
+        # the tensors' device pointers mean nothing to the library.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         lib.gcsadmm_last_error.restype = C.c_char_p
         lib.gcsadmm_last_error.argtypes = [C.c_void_p]

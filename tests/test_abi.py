@@ -18,7 +18,7 @@ def declared_symbols():
 def test_library_exports_header():
     from gcs_admm_amd import build, solver
     build.build()
-    lib = ctypes.CDLL(solver.LIB_PATH)
+    lib = solver.load_library()
     syms = declared_symbols()
     assert len(syms) >= 12
     for s in syms:
