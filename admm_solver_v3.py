@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""``python admm_solver_v3.py --test_file <module in test_data/> [--show_plot <anything>]``
+
+Same command line, case contract (``As, bs, n`` in a ``test_data`` module) and result record as the
+reference's admm_solver_v3.py (:28-60, :735-775); the loop itself (:339-733) runs on the MI355X
+through libgcsadmm.so.  ``--show_plot`` keeps the reference's semantics: only the ABSENT flag means
+True, any supplied value (even "True") is a string and disables the plots (quirk Q6).
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from GCS_utils import compute_cost  # noqa: E402
+from utils import save_data, visualize_results  # noqa: E402
+
+DEFAULT_TEST_FILE = "benchmark2"
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--test_file", type=str, default=DEFAULT_TEST_FILE,
+                        help="The name of the test file (in `test_data` folder) to use (e.g., 'benchmark2').")
+    parser.add_argument("--show_plot", type=str, default=True, help="Whether to display plot.")
+    args = parser.parse_args(argv)
+    print("=======================================================================")
+    print(f"Running ADMM Solver v3 on {args.test_file}")
+    print("=======================================================================\n")
+    test_data_path = os.path.join(HERE, "test_data")
+    sys.path.append(test_data_path)
+    try:
+        mod = importlib.import_module(args.test_file)
+        As, bs, n = mod.As, mod.bs, mod.n
+    except ModuleNotFoundError:
+        print(f"Error: Test file '{args.test_file}' not found in {test_data_path}.")
+        sys.exit(1)
+
+    from gcs_admm_amd.graph import graph_from_sets
+    from gcs_admm_amd.solver import DeviceSolver
+    g = graph_from_sets(As, bs, n)
+    V, E = g.keys, g.edges_as_keys()
+    print(f"V: {V}")
+    print(f"E: {E}")
+    dev = DeviceSolver(g, "f64")
+    MAX_IT = 1000
+    t0 = time.time()
+    res = dev.solve(max_it=MAX_IT)
+    wall = time.time() - t0
+    it = res["iterations"]
+    pri, dual = res["pri_res_seq"], res["dual_res_seq"]
+    for k in range(100, min(it, MAX_IT) + 1, 100):
+        print(f"it = {k}/{MAX_IT}, pri_res_seq[-1]={pri[k]}, dual_res_seq[-1]={dual[k]}")
+    if res["status"] == "converged":
+        if it % 100:
+            print(f"it = {it}/{MAX_IT}, pri_res_seq[-1]={pri[it]}, dual_res_seq[-1]={dual[it]}")
+        print("BREAKING FOR OPT")
+    elif res["status"] == "diverged":
+        print("BREAKING FOR Divergence")
+    xv, zv, yv = dev.xv.cpu().numpy(), dev.zv.cpu().numpy(), dev.yv.cpu().numpy()
+    ye = dev.zedge[2 * n].cpu().numpy()
+    x_v_sol = {v: xv[i] for i, v in enumerate(V)}
+    y_v_sol = {v: float(yv[i]) for i, v in enumerate(V)}
+    z_v_sol = {v: zv[i] for i, v in enumerate(V)}
+    y_e_e_sol = {e: float(ye[i]) for i, e in enumerate(E)}
+    cost = compute_cost(z_v_sol, y_e_e_sol)
+    print(f"x_v: {x_v_sol}")
+    print(f"y_v: {y_v_sol}")
+    print(f"Total solve time: {wall} s.")
+    print(f"Cost before rounding: {cost}")
+    print("===============================================================")
+    print("POST-ROUNDING")
+    print("===============================================================")
+    x_v_rounded = y_v_rounded = None      # rounding + convex restriction: SURVEY.md section 8(f) "next"
+    print(f"{x_v_rounded=}\n")
+    print(f"{y_v_rounded=}\n")
+    if args.show_plot == True:  # noqa: E712  (string semantics on purpose)
+        visualize_results(As, bs, x_v_sol, y_v_sol, x_v_rounded, y_v_rounded)
+    os.makedirs("benchmark_data", exist_ok=True)
+    save_data(f"benchmark_data/admm_solver_v3_{args.test_file}.pkl", As, bs, wall, cost, x_v_sol, y_v_sol,
+              x_v_rounded, y_v_rounded, True, it, res["rho_seq"], res["pri_res_seq"], res["dual_res_seq"])
+    return res
+
+
+if __name__ == "__main__":
+    main()

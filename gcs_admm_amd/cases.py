@@ -22,3 +22,13 @@ def load_fixture(name: str, directory: str | None = None):
     bs = {k: np.array(b, float) for k, b in zip(keys, case["bs"])}
     edges = [(u, w) for u, w in case["edges"]]
     return case, graph_from_sets(As, bs, case["n"], edges=edges)
+
+
+def fixture_sets(name: str):
+    """``As, bs, n, N, M`` of a committed fixture, as a reference-style case module exposes them."""
+    with open(os.path.join(_GOLDEN, f"{name}.json")) as f:
+        case = json.load(f)
+    keys = case["keys"]
+    As = {k: np.array(a, float) for k, a in zip(keys, case["As"])}
+    bs = {k: np.array(b, float) for k, b in zip(keys, case["bs"])}
+    return As, bs, case["n"], case.get("N", 0), case.get("M", 0)
