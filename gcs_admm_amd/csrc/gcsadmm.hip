@@ -31,14 +31,33 @@ constexpr int MAX_SPECIAL_DEG = 256;
 // -------------------------------------------------------------------------------------------------
 // vertex kernel
 // -------------------------------------------------------------------------------------------------
+#ifdef GCS_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[64];
+#endif
+
 template <int N> struct GpuExec {
     Lane<N> &L;
     int lane;
+#ifdef GCS_PHASE_TIMING
+    // diagnostic build only: cycles per barrier-separated phase, summed over wavefronts
+    int phase = 0;
+    unsigned long long *acc;
+    template <class F> __device__ __forceinline__ void each(F &&f)
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        f(L, lane);
+        __syncthreads();
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) acc[phase] += t1 - t0;
+        phase = (phase == 21) ? 5 : phase + 1;   // 5 prologue phases, then 17 per Newton iteration
+    }
+#else
     template <class F> __device__ __forceinline__ void each(F &&f)
     {
         f(L, lane);
         __syncthreads();
     }
+#endif
     template <class P> __device__ __forceinline__ bool all(P &&p) { return __all(p(L) ? 1 : 0) != 0; }
     __device__ __forceinline__ void count(int *c, int fails, int iters)
     {
@@ -60,8 +79,19 @@ __global__ __launch_bounds__(WAVE) void vertex_kernel(VertexArgs<T> a, const gcs
     S.stage = S.lamB + 2 * a.MM * WAVE;
     S.slots = S.stage + RED_CHUNK * WAVE;
     Lane<N> L;
+#ifdef GCS_PHASE_TIMING
+    __shared__ unsigned long long acc[64];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+    __syncthreads();
+    GpuExec<N> ex{L, (int)threadIdx.x, 0, acc};
+#else
     GpuExec<N> ex{L, (int)threadIdx.x};
+#endif
     run_vertex_program<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
+#ifdef GCS_PHASE_TIMING
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&g_phase_cycles[threadIdx.x], acc[threadIdx.x]);
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -632,6 +662,13 @@ gcsadmm_status gcsadmm_cost(gcsadmm_handle h, const gcsadmm_state *st, double ep
     HIPCHK(h, hipGetLastError());
     return GCSADMM_OK;
 }
+
+#ifdef GCS_PHASE_TIMING
+int gcsadmm_debug_phase_cycles(unsigned long long *out64)
+{
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_cycles), 64 * sizeof(unsigned long long));
+}
+#endif
 
 gcsadmm_status gcsadmm_query(gcsadmm_handle h, int32_t *num_waves, int32_t *lds_bytes, int32_t *num_special)
 {

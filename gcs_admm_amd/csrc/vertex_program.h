@@ -28,11 +28,25 @@
 namespace gcs {
 
 constexpr int WAVE = 64;
-constexpr int MAX_SLOTS = 12;    // vertices per wavefront
-constexpr int RED_CHUNK = 24;    // values per cooperative reduction round
+constexpr int MAX_SLOTS = 8;     // vertices per wavefront
+constexpr int RED_CHUNK = 28;    // rows of the reduction staging area (>= the largest round, checked below)
 constexpr double CHOL_SKIP = 1e-12;
 // Tikhonov term (REG_DELTA/2)|w|^2 on every centred unknown (see oracle/gcs_oracle.c REG_DELTA)
 constexpr double REG_DELTA = 1e-7;
+
+// reciprocal: on the device the hardware estimate refined by two Newton steps (the IEEE division
+// sequence costs ~3x as many instructions and the kernel does ~100 of these per Newton iteration)
+GCS_HD double rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
 
 GCS_HD constexpr int PK(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
@@ -42,9 +56,11 @@ template <int N> struct Dim {
     static constexpr int NS = N * (N + 1) / 2, NWS = NW * (NW + 1) / 2, NBS = NB1 * (NB1 + 1) / 2,
                          N2S = N2 * (N2 + 1) / 2;
     // reduction round 1 layout
-    static constexpr int R1_B = 0, R1_BX = NWS, R1_T = R1_BX + NW * N2, R1_XBX = R1_T + NW,
-                         R1_XT = R1_XBX + N2S, R1_XII = R1_XT + N2, R1_W = R1_XII + 2 * NS,
-                         R1_GLX = R1_W + NW, R1_GAP = R1_GLX + N2, R1_RD = R1_GAP + 1, R1_N = R1_RD + 1;
+    // three chunks, each computed right before it is staged:
+    //   A: B_e, the block's unknowns, complementarity, X_ii   B: B_e X_e, B_e(-g)   C: X'BX, X'B(-g)
+    static constexpr int R1_B = 0, R1_W = NWS, R1_GAP = R1_W + NW, R1_XII = R1_GAP + 1, R1A_N = R1_XII + 2 * NS,
+                         R1_BX = R1A_N, R1_T = R1_BX + NW * N2, R1B_N = NW * N2 + NW,
+                         R1_XBX = R1_T + NW, R1_XT = R1_XBX + N2S, R1C_N = N2S + N2, R1_N = R1_XT + N2;
     static constexpr int R2_BASE = R1_N, R2_N = 3;                 // amax (min), c1, c2
     static constexpr int R3_BASE = R2_BASE + R2_N;                 // corrector right-hand sides
     static constexpr int R3_T = 0, R3_XT = NW, R3_GX = NW + N2, R3_N = NW + 2 * N2;
@@ -57,7 +73,7 @@ template <int N> struct Dim {
 template <int N> struct SlotLayout {
     using D = Dim<N>;
     int MM;
-    int A, B, CEN, X, NU, DX, DXA, DNU, SC, SIN, SOUT, BSI, BXS, MF, SIZE;
+    int A, B, CEN, X, NU, DX, DXA, DNU, SC, SIN, SOUT, BSI, BXS, YS, MF, BORD, SIZE;
     GCS_HD explicit SlotLayout(int mm) : MM(mm)
     {
         int o = 0;
@@ -74,7 +90,9 @@ template <int N> struct SlotLayout {
         SOUT = o; o += D::NSUM;
         BSI = o; o += 2 * D::NWS;   // inverse of B_in / B_out
         BXS = o; o += 2 * D::NW * D::N2;
-        MF = o; o += D::NBS;        // Cholesky factor of the reduced border matrix
+        YS = o; o += 2 * D::NW * D::N2;   // Bs^{-1} BXs per side
+        MF = o; o += D::NBS;        // reduced border matrix, then its Cholesky factor
+        BORD = o; o += 7 * D::Q + 3 * D::Q * D::Q + D::N2 + 2 * D::NB + N;   // border-lane state
         SIZE = (o + 1) & ~1;
     }
 };
@@ -109,9 +127,8 @@ template <int NN> GCS_HD void chol_packed(double (&A)[NN * (NN + 1) / 2])
 #endif
             d = diag[j] > 0.0 ? CHOL_SKIP * diag[j] : 1.0;
         }
-        d = sqrt(d);
-        A[PK(j, j)] = d;
-        const double inv = 1.0 / d;
+        const double inv = rcp(sqrt(d));
+        A[PK(j, j)] = inv;          // the diagonal holds 1 / L_jj
 #pragma unroll
         for (int i = j + 1; i < NN; ++i) {
             double s = A[PK(i, j)];
@@ -128,14 +145,55 @@ template <int NN> GCS_HD void chol_solve_packed(const double (&L)[NN * (NN + 1) 
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[PK(i, k)] * b[k];
-        b[i] = s / L[PK(i, i)];
+        b[i] = s * L[PK(i, i)];
     }
 #pragma unroll
     for (int i = NN - 1; i >= 0; --i) {
         double s = b[i];
 #pragma unroll
         for (int k = i + 1; k < NN; ++k) s -= L[PK(k, i)] * b[k];
-        b[i] = s / L[PK(i, i)];
+        b[i] = s * L[PK(i, i)];
+    }
+}
+// the same factorisation / solve on a matrix that lives in LDS (only one row is cached in registers)
+template <int NN> GCS_HD void chol_lds(double *A)
+{
+    double diag[NN];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) diag[j] = A[PK(j, j)];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        double rowj[NN];
+        double d = diag[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) { rowj[k] = A[PK(j, k)]; d -= rowj[k] * rowj[k]; }
+        if (!(d > CHOL_SKIP * diag[j])) d = diag[j] > 0.0 ? CHOL_SKIP * diag[j] : 1.0;
+        const double inv = rcp(sqrt(d));
+        A[PK(j, j)] = inv;
+#pragma unroll
+        for (int i = j + 1; i < NN; ++i) {
+            double s = A[PK(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= A[PK(i, k)] * rowj[k];
+            A[PK(i, j)] = s * inv;
+        }
+    }
+}
+template <int NN> GCS_HD void chol_solve_lds(const double *L, double (&b)[NN])
+{
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[PK(i, k)] * b[k];
+        b[i] = s * L[PK(i, i)];
+    }
+#pragma unroll
+    for (int i = NN - 1; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < NN; ++k) s -= L[PK(k, i)] * b[k];
+        b[i] = s * L[PK(i, i)];
     }
 }
 template <int NN> GCS_HD void chol_inverse_packed(const double (&L)[NN * (NN + 1) / 2], double (&X)[NN * (NN + 1) / 2])
@@ -154,7 +212,7 @@ template <int NN> GCS_HD void chol_inverse_packed(const double (&L)[NN * (NN + 1
 // ---------------------------------------------------------------------------------------------
 // second-order cone of dimension Q = N+1
 // ---------------------------------------------------------------------------------------------
-template <int Q> GCS_HD double soc_det(const double (&s)[Q])
+template <int Q> GCS_HD double soc_det(const double *s)
 {
     double nn = 0;
 #pragma unroll
@@ -162,14 +220,14 @@ template <int Q> GCS_HD double soc_det(const double (&s)[Q])
     nn = sqrt(nn);
     return (s[0] - nn) * (s[0] + nn);
 }
-template <int Q> GCS_HD bool soc_interior(const double (&s)[Q])
+template <int Q> GCS_HD bool soc_interior(const double *s)
 {
     double nn = 0;
 #pragma unroll
     for (int k = 1; k < Q; ++k) nn += s[k] * s[k];
     return s[0] > sqrt(nn);
 }
-template <int Q> GCS_HD double soc_max_step(const double (&s)[Q], const double (&ds)[Q])
+template <int Q> GCS_HD double soc_max_step(const double *s, const double *ds)
 {
     double a = ds[0] * ds[0], b = s[0] * ds[0];
     const double c = soc_det<Q>(s);
@@ -193,8 +251,7 @@ template <int Q> GCS_HD double soc_max_step(const double (&s)[Q], const double (
     return al;
 }
 // Nesterov-Todd scaling W (symmetric, full QxQ): W lam = W^{-1} s.  Returns false on a boundary point.
-template <int Q> GCS_HD bool soc_scaling(const double (&s)[Q], const double (&z)[Q], double (&W)[Q * Q], double (&Wi)[Q * Q],
-                                         double (&wb)[Q], double &eta)
+template <int Q> GCS_HD bool soc_scaling(const double *s, const double *z, double *W, double *Wi, double *wb, double &eta)
 {
     const double ss = soc_det<Q>(s), zz = soc_det<Q>(z);
     if (!(ss > 0.0) || !(zz > 0.0)) return false;
@@ -244,18 +301,16 @@ template <int N> struct Lane {
     double Bm[D::NWS];             // block: inverse of the block Hessian
     double P1[2 * D::N2 + 1], P2[2 * D::N2 + 1]; // G'(1/s) and G'(corr/s): parts p, y, x
     double gk[2 * D::N2 + 1];      // G' kappa
-    double gl[2 * D::N2 + 1];      // G' lambda (dual residual part)
     double l5, l6;                 // duals of 0 <= y <= 1
     double amax, c1, c2, gap;
     // border lane only
-    double t, lsoc[D::Q], x[D::N2];
-    double W[D::Q * D::Q], Wi[D::Q * D::Q], W2[D::Q * D::Q], lt[D::Q];
-    double soc_c0, soc_cv[N];      // W^{-2} = [c0 cv'; cv C11]; t is eliminated by hand
-    double dba[D::NB], db[D::NB];
-    double dssa[D::Q], dlsa[D::Q], dss[D::Q], dls[D::Q], ksoc[D::Q];
-    double mu, scale;
+    // (arrays live in the vertex's LDS slot: only one lane per vertex touches them, and keeping them
+    //  in registers would charge every lane of the wavefront for them)
+    double t, soc_c0, mu, scale;   // W^{-2} = [c0 cv'; cv C11]; t is eliminated by hand
+    double *lsoc, *x, *W, *Wi, *W2, *lt, *soc_cv, *dba, *db, *dssa, *dlsa, *dss, *dls, *ksoc;
     int iters, status, done, stalled, bad;
-    double vals[D::R1_N];          // staging values of the current reduction round
+    double BX[D::NW * D::N2], t0[D::NW];   // block: B_e X_e and B_e(-g0), kept from chunk B to chunk C
+    double scale0;
 };
 
 struct WaveShared {
@@ -314,10 +369,11 @@ GCS_HD void pass_A_half(Lane<N> &L, const double *A, const double *bc, const dou
     rows_half<N, I>(L, A, bc, x, [&](int j, const double(&a)[N], double b, double sa, double sb) {
         double &ra = la[(I * MM + j) * WAVE + lane];
         double &rb = lb[(I * MM + j) * WAVE + lane];
-        if (first) { ra = 1.0 / sa; rb = 1.0 / sb; }
+        const double isa = rcp(sa), isb = rcp(sb);
+        if (first) { ra = isa; rb = isb; }
         if (!(sa > 0.0) || !(sb > 0.0)) L.bad = 1;
         const double l_a = ra, l_b = rb;
-        const double Da = l_a / sa, Db = l_b / sb, Ds = Da + Db;
+        const double Da = l_a * isa, Db = l_b * isb, Ds = Da + Db;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
 #pragma unroll
@@ -327,11 +383,8 @@ GCS_HD void pass_A_half(Lane<N> &L, const double *A, const double *bc, const dou
             }
             kiy[k] -= Ds * b * a[k];
             xyi[k] += Db * b * a[k];
-            L.gl[I * N + k] += a[k] * (l_a - l_b);
-            L.gl[2 * N + 1 + I * N + k] += a[k] * l_b;
         }
         L.kyy += Ds * b * b;
-        L.gl[2 * N] += b * (l_b - l_a);
         L.gap += sa * l_a + sb * l_b;
     });
 }
@@ -347,17 +400,15 @@ GCS_HD void pass_A(Lane<N> &L, const WaveShared &S, const SlotLayout<N> &SL, int
     for (int k = 0; k < D::NS; ++k) { L.K1[k] = L.K2[k] = L.X1[k] = L.X2[k] = 0; }
 #pragma unroll
     for (int k = 0; k < N; ++k) { L.k1y[k] = L.k2y[k] = L.xy1[k] = L.xy2[k] = 0; }
-#pragma unroll
-    for (int k = 0; k < 2 * D::N2 + 1; ++k) L.gl[k] = 0;
     L.kyy = 0; L.gap = 0; L.bad = 0;
     pass_A_half<N, 0>(L, A, bc, x, S.lamA, S.lamB, S.MM, lane, first, L.K1, L.k1y, L.X1, L.xy1);
     pass_A_half<N, 1>(L, A, bc, x, S.lamA, S.lamB, S.MM, lane, first, L.K2, L.k2y, L.X2, L.xy2);
     // bounds 0 <= yy <= 1
     {
         const double s5 = L.yy, s6 = 1.0 - L.yy;
-        if (first) { L.l5 = 1.0 / s5; L.l6 = 1.0 / s6; }
-        L.kyy += L.l5 / s5 + L.l6 / s6;
-        L.gl[2 * N] += -L.l5 + L.l6;
+        const double is5 = rcp(s5), is6 = rcp(s6);
+        if (first) { L.l5 = is5; L.l6 = is6; }
+        L.kyy += L.l5 * is5 + L.l6 * is6;
         L.gap += s5 * L.l5 + s6 * L.l6;
         if (!(s5 > 0.0) || !(s6 > 0.0)) L.bad = 1;
     }
@@ -418,8 +469,8 @@ template <int N> GCS_HD void block_factor(Lane<N> &L)
         double s1 = L.k1y[i], s2 = L.k2y[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) { s1 -= F1[PK(i, k)] * l1[k]; s2 -= F2[PK(i, k)] * l2[k]; }
-        l1[i] = s1 / F1[PK(i, i)];
-        l2[i] = s2 / F2[PK(i, i)];
+        l1[i] = s1 * F1[PK(i, i)];
+        l2[i] = s2 * F2[PK(i, i)];
     }
     double dy = L.kyy;
 #pragma unroll
@@ -430,7 +481,7 @@ template <int N> GCS_HD void block_factor(Lane<N> &L)
 #endif
         dy = L.kyy > 0.0 ? CHOL_SKIP * L.kyy : 1.0;
     }
-    const double isy = 1.0 / dy;
+    const double isy = rcp(dy);
     // u_i = K_i^{-1} k_iy = L_i^{-T} l_i
     double u1[N], u2[N];
 #pragma unroll
@@ -438,8 +489,8 @@ template <int N> GCS_HD void block_factor(Lane<N> &L)
         double s1 = l1[i], s2 = l2[i];
 #pragma unroll
         for (int k = i + 1; k < N; ++k) { s1 -= F1[PK(k, i)] * u1[k]; s2 -= F2[PK(k, i)] * u2[k]; }
-        u1[i] = s1 / F1[PK(i, i)];
-        u2[i] = s2 / F2[PK(i, i)];
+        u1[i] = s1 * F1[PK(i, i)];
+        u2[i] = s2 * F2[PK(i, i)];
     }
     double I1[D::NS], I2[D::NS];
     chol_inverse_packed<N>(F1, I1);
@@ -498,15 +549,38 @@ template <int N> GCS_HD void XT_apply(const Lane<N> &L, const double (&t)[2 * N 
     }
 }
 
-// values of reduction round 1 for a block lane (vals has Dim<N>::R1_N entries)
-template <int N> GCS_HD void block_round1(Lane<N> &L, double (&vals)[Dim<N>::R1_N])
+// reduction round 1 of a block lane, written straight into the staging area chunk by chunk
+template <int N> GCS_HD void block_chunk_A(Lane<N> &L, double *stage, int lane, bool active)
 {
     using D = Dim<N>;
+    static_assert(D::R1A_N <= RED_CHUNK && D::R1B_N <= RED_CHUNK && D::R1C_N <= RED_CHUNK && D::R3_N <= RED_CHUNK, "RED_CHUNK too small");
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < D::R1A_N; ++k) stage[k * WAVE + lane] = 0.0;
+        return;
+    }
     block_factor<N>(L);
 #pragma unroll
-    for (int k = 0; k < D::NWS; ++k) vals[D::R1_B + k] = L.Bm[k];
+    for (int k = 0; k < D::NWS; ++k) stage[(D::R1_B + k) * WAVE + lane] = L.Bm[k];
+#pragma unroll
+    for (int k = 0; k < D::N2; ++k) stage[(D::R1_W + k) * WAVE + lane] = L.p[k];
+    stage[(D::R1_W + D::N2) * WAVE + lane] = L.yy;
+    stage[D::R1_GAP * WAVE + lane] = L.gap;
+#pragma unroll
+    for (int k = 0; k < D::NS; ++k) {
+        stage[(D::R1_XII + k) * WAVE + lane] = L.X1[k];
+        stage[(D::R1_XII + D::NS + k) * WAVE + lane] = L.X2[k];
+    }
+}
+template <int N> GCS_HD void block_chunk_B(Lane<N> &L, double *stage, int lane, bool active)
+{
+    using D = Dim<N>;
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < D::R1B_N; ++k) stage[k * WAVE + lane] = 0.0;
+        return;
+    }
     // BX columns: B * X e_c
-    double BX[D::NW][D::N2];
 #pragma unroll
     for (int c = 0; c < D::N2; ++c) {
         double col[D::NW], e[D::N2], bc_[D::NW];
@@ -515,40 +589,37 @@ template <int N> GCS_HD void block_round1(Lane<N> &L, double (&vals)[Dim<N>::R1_
         X_apply<N>(L, e, col);
         block_apply<N>(L, col, bc_);
 #pragma unroll
-        for (int i = 0; i < D::NW; ++i) { BX[i][c] = bc_[i]; vals[D::R1_BX + i * D::N2 + c] = bc_[i]; }
+        for (int i = 0; i < D::NW; ++i) { L.BX[i * D::N2 + c] = bc_[i]; stage[(i * D::N2 + c) * WAVE + lane] = bc_[i]; }
+    }
+    double r[D::NW];
+#pragma unroll
+    for (int k = 0; k < D::NW; ++k) r[k] = -L.g0[k];
+    block_apply<N>(L, r, L.t0);
+#pragma unroll
+    for (int k = 0; k < D::NW; ++k) stage[(D::NW * D::N2 + k) * WAVE + lane] = L.t0[k];
+}
+template <int N> GCS_HD void block_chunk_C(Lane<N> &L, double *stage, int lane, bool active)
+{
+    using D = Dim<N>;
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < D::R1C_N; ++k) stage[k * WAVE + lane] = 0.0;
+        return;
     }
     // XBX = X' (B X)
 #pragma unroll
     for (int c = 0; c < D::N2; ++c) {
         double col[D::NW], xt[D::N2];
 #pragma unroll
-        for (int i = 0; i < D::NW; ++i) col[i] = BX[i][c];
+        for (int i = 0; i < D::NW; ++i) col[i] = L.BX[i * D::N2 + c];
         XT_apply<N>(L, col, xt);
 #pragma unroll
-        for (int a = c; a < D::N2; ++a) vals[D::R1_XBX + PK(a, c)] = xt[a];
+        for (int a = c; a < D::N2; ++a) stage[PK(a, c) * WAVE + lane] = xt[a];
     }
-    // t0 = B(-g0), X' t0
-    double r[D::NW], t0[D::NW], xt0[D::N2];
+    double xt0[D::N2];
+    XT_apply<N>(L, L.t0, xt0);
 #pragma unroll
-    for (int k = 0; k < D::NW; ++k) r[k] = -L.g0[k];
-    block_apply<N>(L, r, t0);
-    XT_apply<N>(L, t0, xt0);
-#pragma unroll
-    for (int k = 0; k < D::NW; ++k) vals[D::R1_T + k] = t0[k];
-#pragma unroll
-    for (int k = 0; k < D::N2; ++k) vals[D::R1_XT + k] = xt0[k];
-#pragma unroll
-    for (int k = 0; k < D::NS; ++k) { vals[D::R1_XII + k] = L.X1[k]; vals[D::R1_XII + D::NS + k] = L.X2[k]; }
-#pragma unroll
-    for (int k = 0; k < D::N2; ++k) vals[D::R1_W + k] = L.p[k];
-    vals[D::R1_W + D::N2] = L.yy;
-#pragma unroll
-    for (int k = 0; k < D::N2; ++k) vals[D::R1_GLX + k] = L.gl[D::NW + k];
-    vals[D::R1_GAP] = L.gap;
-    double rd = 0;
-#pragma unroll
-    for (int k = 0; k < D::NW; ++k) rd = fmax(rd, fabs(L.g0[k] + L.gl[k]));
-    vals[D::R1_RD] = rd;
+    for (int k = 0; k < D::N2; ++k) stage[(D::N2S + k) * WAVE + lane] = xt0[k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -593,7 +664,7 @@ template <int N> struct BorderIdx {
 template <int N>
 GCS_HD void border_solve(Lane<N> &L, double *sl, const SlotLayout<N> &SL, const double (&gb)[Dim<N>::NB],
                          const double *tin, const double *tout, const double *xtin, const double *xtout,
-                         const double (&rp)[2][Dim<N>::NW], double (&db)[Dim<N>::NB], int dxoff)
+                         const double (&rp)[2][Dim<N>::NW], double *db, int dxoff)
 {
     using D = Dim<N>;
     double rhs[D::NB];
@@ -637,10 +708,7 @@ GCS_HD void border_solve(Lane<N> &L, double *sl, const SlotLayout<N> &SL, const 
         for (int k = 0; k < N; ++k) { r1[BI::Z1 + k] += L.soc_cv[k] * gt; r1[BI::Z2 + k] -= L.soc_cv[k] * gt; }
 #pragma unroll
         for (int k = 0; k < N; ++k) r1[BI::Z2 + k] += r1[BI::Z1 + k];   // rhs in the (u, z_2) variables
-        double Mf[D::NBS];
-#pragma unroll
-        for (int k = 0; k < D::NBS; ++k) Mf[k] = sl[SL.MF + k];
-        chol_solve_packed<D::NB1>(Mf, r1);
+        chol_solve_lds<D::NB1>(sl + SL.MF, r1);
 #pragma unroll
         for (int k = 0; k < N; ++k) r1[BI::Z1 + k] += r1[BI::Z2 + k];   // dz_1 = du + dz_2
 #pragma unroll
@@ -704,19 +772,8 @@ GCS_HD void border_factor_and_affine(Lane<N> &L, const WaveShared &S, const Slot
         rp[1][k] = zeta - sout[D::R1_W + k];
         rpmax = fmax(rpmax, fmax(fabs(rp[0][k]), fabs(rp[1][k])));
     }
-    double rdmax = fmax(sin[D::R1_RD], sout[D::R1_RD]);
-    // border dual residual: x rows, zeta rows (with the cone multiplier), t row
-#pragma unroll
-    for (int k = 0; k < D::N2; ++k) rdmax = fmax(rdmax, fabs(L.gl[D::NW + k] + sin[D::R1_GLX + k] + sout[D::R1_GLX + k]));
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        rdmax = fmax(rdmax, fabs(L.g0[k] + L.gl[k] - L.lsoc[1 + k]));
-        rdmax = fmax(rdmax, fabs(L.g0[N + k] + L.gl[N + k] + L.lsoc[1 + k]));
-    }
-    rdmax = fmax(rdmax, fabs(L.g0[2 * N] + L.gl[2 * N]));
-    rdmax = fmax(rdmax, fabs(1.0 - L.lsoc[0]));
     // stop on the barrier parameter alone (see oracle/gcs_oracle.c): insensitive to solve round-off
-    (void)rdmax; (void)rpmax;
+    (void)rpmax;
     // a vanishing step (stalled) means the linear algebra has run out of precision: accept the point if
     // the barrier parameter is within 1e3 of the target
     const bool conv = mu <= ipm_tol || (L.stalled && mu <= 1e3 * ipm_tol);
@@ -750,54 +807,7 @@ GCS_HD void border_factor_and_affine(Lane<N> &L, const WaveShared &S, const Slot
         for (int k = 0; k < D::Q; ++k) a += L.W[i * D::Q + k] * L.lsoc[k];
         L.lt[i] = a;
     }
-    // ---- reduced border matrix M (packed lower, order x1 x2 z1 z2 yv t) ----
-    double M[D::NBS];
-#pragma unroll
-    for (int k = 0; k < D::NBS; ++k) M[k] = 0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-#pragma unroll
-        for (int l = 0; l <= k; ++l) {
-            M[PK(BI::Z1 + k, BI::Z1 + l)] += L.K1[PK(k, l)];
-            M[PK(BI::Z2 + k, BI::Z2 + l)] += L.K2[PK(k, l)];
-            M[PK(BI::X1 + k, BI::X1 + l)] += L.X1[PK(k, l)] + sin[D::R1_XII + PK(k, l)] + sout[D::R1_XII + PK(k, l)];
-            M[PK(BI::X2 + k, BI::X2 + l)] += L.X2[PK(k, l)] + sin[D::R1_XII + D::NS + PK(k, l)] + sout[D::R1_XII + D::NS + PK(k, l)];
-        }
-#pragma unroll
-        for (int l = 0; l < N; ++l) {
-            M[PK(BI::Z1 + k, BI::X1 + l)] -= L.X1[PK(k, l)];
-            M[PK(BI::Z2 + k, BI::X2 + l)] -= L.X2[PK(k, l)];
-        }
-        M[PK(BI::YV, BI::Z1 + k)] += L.k1y[k];
-        M[PK(BI::YV, BI::Z2 + k)] += L.k2y[k];
-        M[PK(BI::YV, BI::X1 + k)] += L.xy1[k];
-        M[PK(BI::YV, BI::X2 + k)] += L.xy2[k];
-    }
-    // Cone block.  With W^{-2} = eta^{-2}(2 v v' - J), v = (wb0, -wb1), eliminating t first leaves on
-    // u = z_1 - z_2 the Schur complement Su = eta^{-2}(I - 2 wb1 wb1'/(2 wb0^2 - 1)), formed from this
-    // closed form: a numerical pivot on t cancels catastrophically once the cone is active.
-    double Su[N * N];
-    {
-        const double ie2 = 1.0 / (eta * eta), g2 = 2.0 / (2.0 * wb[0] * wb[0] - 1.0);
-        L.soc_c0 = ie2 * (2.0 * wb[0] * wb[0] - 1.0);
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            L.soc_cv[k] = -ie2 * 2.0 * wb[0] * wb[1 + k];
-#pragma unroll
-            for (int l = 0; l < N; ++l) {
-                Su[k * N + l] = ie2 * ((k == l ? 1.0 : 0.0) - g2 * wb[1 + k] * wb[1 + l]);
-            }
-        }
-    }
-    M[PK(BI::YV, BI::YV)] += L.kyy;
-#pragma unroll
-    for (int k = 0; k < D::N2; ++k) M[PK(k, k)] += REG_DELTA;
-    // - sum_e X'BX on the x block
-#pragma unroll
-    for (int a = 0; a < D::N2; ++a)
-#pragma unroll
-        for (int c = 0; c <= a; ++c) M[PK(a, c)] -= sin[D::R1_XBX + PK(a, c)] + sout[D::R1_XBX + PK(a, c)];
-    // per side: factor B_s, inverse, Y = Bsi BXs, add to M
+    // ---- per side: factor B_s, inverse, Y_s = Bs^{-1} BXs (all kept in the LDS slot) ----
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const double *sum = s ? sout : sin;
@@ -808,7 +818,6 @@ GCS_HD void border_factor_and_affine(Lane<N> &L, const WaveShared &S, const Slot
         chol_inverse_packed<D::NW>(Bs, Bsi);
 #pragma unroll
         for (int k = 0; k < D::NWS; ++k) sl[SL.BSI + s * D::NWS + k] = Bsi[k];
-        double Y[D::NW][D::N2];
 #pragma unroll
         for (int i = 0; i < D::NW; ++i)
 #pragma unroll
@@ -816,49 +825,83 @@ GCS_HD void border_factor_and_affine(Lane<N> &L, const WaveShared &S, const Slot
                 double a = 0;
 #pragma unroll
                 for (int k = 0; k < D::NW; ++k) a += Bsi[PK(i, k)] * sum[D::R1_BX + k * D::N2 + c];
-                Y[i][c] = a;
+                sl[SL.YS + s * D::NW * D::N2 + i * D::N2 + c] = a;
                 sl[SL.BXS + s * D::NW * D::N2 + i * D::N2 + c] = sum[D::R1_BX + i * D::N2 + c];
             }
+    }
+    // ---- reduced border matrix M (packed lower, order x1 x2 z1 z2 yv), assembled entry by entry in LDS ----
+    double *M = sl + SL.MF;
+    const double *Y0 = sl + SL.YS, *Y1 = sl + SL.YS + D::NW * D::N2;
+    const double *BX0 = sl + SL.BXS, *BX1 = sl + SL.BXS + D::NW * D::N2;
+    const double *Bi0 = sl + SL.BSI, *Bi1 = sl + SL.BSI + D::NWS;
+    // x-x block
 #pragma unroll
-        for (int a = 0; a < D::N2; ++a)
+    for (int a = 0; a < D::N2; ++a)
 #pragma unroll
-            for (int c = 0; c <= a; ++c) {
-                double acc = 0;
+        for (int c = 0; c <= a; ++c) {
+            double v = (a == c ? REG_DELTA : 0.0) - (sin[D::R1_XBX + PK(a, c)] + sout[D::R1_XBX + PK(a, c)]);
+            if (a < N && c < N) v += L.X1[PK(a, c)] + sin[D::R1_XII + PK(a, c)] + sout[D::R1_XII + PK(a, c)];
+            if (a >= N && c >= N) v += L.X2[PK(a - N, c - N)] + sin[D::R1_XII + D::NS + PK(a - N, c - N)] + sout[D::R1_XII + D::NS + PK(a - N, c - N)];
 #pragma unroll
-                for (int k = 0; k < D::NW; ++k) acc += sum[D::R1_BX + k * D::N2 + a] * Y[k][c];
-                M[PK(a, c)] += acc;
-            }
+            for (int k = 0; k < D::NW; ++k) v += BX0[k * D::N2 + a] * Y0[k * D::N2 + c] + BX1[k * D::N2 + a] * Y1[k * D::N2 + c];
+            M[PK(a, c)] = v;
+        }
+    // zeta-x block (rows z1, z2, yv ; columns x1, x2)
 #pragma unroll
-        for (int i = 0; i < D::NW; ++i) {
+    for (int i = 0; i < D::NW; ++i)
 #pragma unroll
-            for (int c = 0; c < D::N2; ++c) M[PK(D::N2 + i, c)] += Y[i][c];
+        for (int c = 0; c < D::N2; ++c) {
+            double v = Y0[i * D::N2 + c] + Y1[i * D::N2 + c];
+            if (i < N && c < N) v -= L.X1[PK(i, c)];
+            if (i >= N && i < D::N2 && c >= N) v -= L.X2[PK(i - N, c - N)];
+            if (i == D::N2) v += (c < N) ? L.xy1[c] : L.xy2[c - N];
+            M[PK(D::N2 + i, c)] = v;
+        }
+    // zeta-zeta block
 #pragma unroll
-            for (int k = 0; k <= i; ++k) M[PK(D::N2 + i, D::N2 + k)] += Bsi[PK(i, k)];
+    for (int i = 0; i < D::NW; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) {
+            double v = Bi0[PK(i, k)] + Bi1[PK(i, k)];
+            if (i < N) v += L.K1[PK(i, k)];
+            if (i >= N && i < D::N2 && k >= N) v += L.K2[PK(i - N, k - N)];
+            if (i == D::N2) v += (k < N) ? L.k1y[k] : (k < D::N2 ? L.k2y[k - N] : L.kyy);
+            M[PK(D::N2 + i, D::N2 + k)] = v;
+        }
+    // Cone block.  With W^{-2} = eta^{-2}(2 v v' - J), v = (wb0, -wb1), eliminating t first leaves on
+    // u = z_1 - z_2 the Schur complement Su = eta^{-2}(I - 2 wb1 wb1'/(2 wb0^2 - 1)), formed from this
+    // closed form: a numerical pivot on t cancels catastrophically once the cone is active.
+    double Su[N * N];
+    {
+        const double ie2 = rcp(eta * eta), g2 = 2.0 * rcp(2.0 * wb[0] * wb[0] - 1.0);
+        L.soc_c0 = ie2 * (2.0 * wb[0] * wb[0] - 1.0);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            L.soc_cv[k] = -ie2 * 2.0 * wb[0] * wb[1 + k];
+#pragma unroll
+            for (int l = 0; l < N; ++l) Su[k * N + l] = ie2 * ((k == l ? 1.0 : 0.0) - g2 * wb[1 + k] * wb[1 + l]);
         }
     }
     // Change of variables (u, z_2) = (z_1 - z_2, z_2): the cone term then sits on u alone.  In (z_1, z_2)
     // it enters as [Su -Su; -Su Su] and, with the cone inactive (t -> 0), Su grows like 1/mu, so that
     // eliminating z_1 before z_2 would cancel K_2 + Su - Su (K_1 + Su)^{-1} Su.
-    {
-        double Mp[D::NBS];
-#pragma unroll
-        for (int i = 0; i < D::NB1; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                const bool zi = i >= BI::Z2 && i < BI::Z2 + N, zj = j >= BI::Z2 && j < BI::Z2 + N;
-                double a = M[PK(i, j)];
-                if (zi) a += M[PK(i - N, j)];
-                if (zj) a += M[PK(i, j - N)];
-                if (zi && zj) a += M[PK(i - N, j - N)];
-                Mp[PK(i, j)] = a;
-            }
+    {   // in place: first the (z2', z2') block, which needs the untouched cross entries, then the rest
 #pragma unroll
         for (int k = 0; k < N; ++k)
 #pragma unroll
-            for (int l = 0; l <= k; ++l) Mp[PK(BI::Z1 + k, BI::Z1 + l)] += Su[k * N + l];
-        chol_packed<D::NB1>(Mp);
+            for (int l = 0; l <= k; ++l)
+                M[PK(BI::Z2 + k, BI::Z2 + l)] += M[PK(BI::Z1 + k, BI::Z2 + l)] + M[PK(BI::Z2 + k, BI::Z1 + l)] + M[PK(BI::Z1 + k, BI::Z1 + l)];
 #pragma unroll
-        for (int k = 0; k < D::NBS; ++k) sl[SL.MF + k] = Mp[k];
+        for (int i = 0; i < D::NB1; ++i) {
+            if (i >= BI::Z2 && i < BI::Z2 + N) continue;
+#pragma unroll
+            for (int k = 0; k < N; ++k) M[PK(i, BI::Z2 + k)] += M[PK(i, BI::Z1 + k)];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int l = 0; l <= k; ++l) M[PK(BI::Z1 + k, BI::Z1 + l)] += Su[k * N + l];
+        chol_lds<D::NB1>(M);
     }
     // ---- affine direction (kappa = 0) ----
     double gb[D::NB];
@@ -885,7 +928,7 @@ GCS_HD void lane_direction(Lane<N> &L, const double *sl, const SlotLayout<N> &SL
         for (int k = 0; k < D::NW; ++k) r[k] = -(L.g0[k] + (affine ? 0.0 : L.gk[k])) + dnu[k] - xd[k];
         block_apply<N>(L, r, dp);
     } else {
-        const double(&db)[D::NB] = affine ? L.dba : L.db;
+        const double *db = affine ? L.dba : L.db;
 #pragma unroll
         for (int k = 0; k < D::NW; ++k) dp[k] = db[D::N2 + k];
     }
@@ -900,14 +943,13 @@ GCS_HD void pass_B_half(Lane<N> &L, const double *A, const double *bc, const dou
         const double l_a = la[(I * MM + j) * WAVE + lane], l_b = lb[(I * MM + j) * WAVE + lane];
         double dsa, dsb;
         row_dir<N, I>(a, b, L.dpa, dxa, dsa, dsb);
-        const double dla = -l_a - (l_a / sa) * dsa, dlb = -l_b - (l_b / sb) * dsb;
-        if (dsa < 0) L.amax = fmin(L.amax, -sa / dsa);
-        if (dla < 0) L.amax = fmin(L.amax, -l_a / dla);
-        if (dsb < 0) L.amax = fmin(L.amax, -sb / dsb);
-        if (dlb < 0) L.amax = fmin(L.amax, -l_b / dlb);
+        const double ia = rcp(sa), ib = rcp(sb);
+        const double qsa = dsa * ia, qsb = dsb * ib;                 // ds / s
+        const double dla = -l_a - l_a * qsa, dlb = -l_b - l_b * qsb; // kappa = 0:  dl / l = -1 - ds / s
+        // largest -ds/s and -dl/l over the rows; the step bound is its reciprocal
+        L.amax = fmax(L.amax, fmax(fmax(-qsa, 1.0 + qsa), fmax(-qsb, 1.0 + qsb)));
         L.c1 += sa * dla + l_a * dsa + sb * dlb + l_b * dsb;
         L.c2 += dsa * dla + dsb * dlb;
-        const double ia = 1.0 / sa, ib = 1.0 / sb;
         const double qa = dsa * dla * ia, qb = dsb * dlb * ib;
         // G rows: a-type (+a on p_i, -b on y), b-type (-a on p_i, +b on y, +a on x_i)
 #pragma unroll
@@ -930,7 +972,7 @@ GCS_HD void pass_B(Lane<N> &L, const WaveShared &S, const SlotLayout<N> &SL, int
     double *sl = slot_ptr<N>(S, SL, L.slot);
     if (sl[SL.SC + 2] != 0.0) { L.done = 1; return; }
     lane_direction<N>(L, sl, SL, true, L.dpa);
-    L.amax = 1e300; L.c1 = 0; L.c2 = 0;
+    L.amax = 0.0; L.c1 = 0; L.c2 = 0;   // amax holds the largest ratio until the end of the pass
 #pragma unroll
     for (int k = 0; k < 2 * D::N2 + 1; ++k) { L.P1[k] = 0; L.P2[k] = 0; }
     const double *dxa = sl + SL.DXA, *x = sl + SL.X + par * D::N2;
@@ -938,16 +980,15 @@ GCS_HD void pass_B(Lane<N> &L, const WaveShared &S, const SlotLayout<N> &SL, int
     pass_B_half<N, 1>(L, sl + SL.A, sl + SL.B, x, dxa, S.lamA, S.lamB, S.MM, lane);
     {   // bounds: s5 = yy (G = -1), s6 = 1 - yy (G = +1)
         const double s5 = L.yy, s6 = 1.0 - L.yy, ds5 = L.dpa[2 * N], ds6 = -L.dpa[2 * N];
-        const double dl5 = -L.l5 - (L.l5 / s5) * ds5, dl6 = -L.l6 - (L.l6 / s6) * ds6;
-        if (ds5 < 0) L.amax = fmin(L.amax, -s5 / ds5);
-        if (dl5 < 0) L.amax = fmin(L.amax, -L.l5 / dl5);
-        if (ds6 < 0) L.amax = fmin(L.amax, -s6 / ds6);
-        if (dl6 < 0) L.amax = fmin(L.amax, -L.l6 / dl6);
+        const double i5 = rcp(s5), i6 = rcp(s6), q5 = ds5 * i5, q6 = ds6 * i6;
+        const double dl5 = -L.l5 - L.l5 * q5, dl6 = -L.l6 - L.l6 * q6;
+        L.amax = fmax(L.amax, fmax(fmax(-q5, 1.0 + q5), fmax(-q6, 1.0 + q6)));
         L.c1 += s5 * dl5 + L.l5 * ds5 + s6 * dl6 + L.l6 * ds6;
         L.c2 += ds5 * dl5 + ds6 * dl6;
-        L.P1[2 * N] += -1.0 / s5 + 1.0 / s6;
-        L.P2[2 * N] += -(ds5 * dl5) / s5 + (ds6 * dl6) / s6;
+        L.P1[2 * N] += -i5 + i6;
+        L.P2[2 * N] += -(ds5 * dl5) * i5 + (ds6 * dl6) * i6;
     }
+    L.amax = L.amax > 0.0 ? rcp(L.amax) : 1e300;
     if (L.role == BORDER) {
         using BI = BorderIdx<N>;
         double ssoc[D::Q];
@@ -1086,20 +1127,19 @@ GCS_HD void pass_DE_half(Lane<N> &L, const double *A, const double *bc, const do
     rows_half<N, I>(L, A, bc, x, [&](int j, const double(&a)[N], double b, double sa, double sb) {
         double &ra = la[(I * MM + j) * WAVE + lane];
         double &rb = lb[(I * MM + j) * WAVE + lane];
-        const double l_a = ra, l_b = rb, Da = l_a / sa, Db = l_b / sb;
+        const double isa = rcp(sa), isb = rcp(sb);
+        const double l_a = ra, l_b = rb, Da = l_a * isa, Db = l_b * isb;
         double dsa0, dsb0, dsa, dsb;
         row_dir<N, I>(a, b, L.dpa, dxa, dsa0, dsb0);
         row_dir<N, I>(a, b, L.dp, dx, dsa, dsb);
-        const double ka = (sm - dsa0 * (-l_a - Da * dsa0)) / sa, kb = (sm - dsb0 * (-l_b - Db * dsb0)) / sb;
+        const double ka = (sm - dsa0 * (-l_a - Da * dsa0)) * isa, kb = (sm - dsb0 * (-l_b - Db * dsb0)) * isb;
         const double dla = ka - l_a - Da * dsa, dlb = kb - l_b - Db * dsb;
         if (APPLY) {
             ra = l_a + alpha * dla;
             rb = l_b + alpha * dlb;
         } else {
-            if (dsa < 0) L.amax = fmin(L.amax, -sa / dsa);
-            if (dla < 0) L.amax = fmin(L.amax, -l_a / dla);
-            if (dsb < 0) L.amax = fmin(L.amax, -sb / dsb);
-            if (dlb < 0) L.amax = fmin(L.amax, -l_b / dlb);
+            // largest -ds/s and -dl/l; the step bound is the reciprocal (taken once, in pass_DE)
+            L.amax = fmax(L.amax, fmax(fmax(-dsa * isa, -dla * rcp(l_a)), fmax(-dsb * isb, -dlb * rcp(l_b))));
         }
     });
 }
@@ -1119,24 +1159,23 @@ GCS_HD void pass_DE(Lane<N> &L, const WaveShared &S, const SlotLayout<N> &SL, in
         } else {
             lane_direction<N>(L, sl, SL, false, L.dp);
         }
-        L.amax = 1e300;
+        L.amax = 0.0;   // largest ratio until converted below
     }
     const double *x = sl + SL.X + par * D::N2;
     pass_DE_half<N, 0, APPLY>(L, sl + SL.A, sl + SL.B, x, sl + SL.DXA, sl + SL.DX, S.lamA, S.lamB, S.MM, lane, sm, alpha);
     pass_DE_half<N, 1, APPLY>(L, sl + SL.A, sl + SL.B, x, sl + SL.DXA, sl + SL.DX, S.lamA, S.lamB, S.MM, lane, sm, alpha);
     {
         const double s5 = L.yy, s6 = 1.0 - L.yy;
-        const double D5 = L.l5 / s5, D6 = L.l6 / s6;
+        const double i5 = rcp(s5), i6 = rcp(s6);
+        const double D5 = L.l5 * i5, D6 = L.l6 * i6;
         const double d50 = L.dpa[2 * N], d60 = -L.dpa[2 * N], d5 = L.dp[2 * N], d6 = -L.dp[2 * N];
-        const double k5 = (sm - d50 * (-L.l5 - D5 * d50)) / s5, k6 = (sm - d60 * (-L.l6 - D6 * d60)) / s6;
+        const double k5 = (sm - d50 * (-L.l5 - D5 * d50)) * i5, k6 = (sm - d60 * (-L.l6 - D6 * d60)) * i6;
         const double dl5 = k5 - L.l5 - D5 * d5, dl6 = k6 - L.l6 - D6 * d6;
         if (APPLY) {
             L.l5 += alpha * dl5; L.l6 += alpha * dl6;
         } else {
-            if (d5 < 0) L.amax = fmin(L.amax, -s5 / d5);
-            if (dl5 < 0) L.amax = fmin(L.amax, -L.l5 / dl5);
-            if (d6 < 0) L.amax = fmin(L.amax, -s6 / d6);
-            if (dl6 < 0) L.amax = fmin(L.amax, -L.l6 / dl6);
+            L.amax = fmax(L.amax, fmax(fmax(-d5 * i5, -dl5 * rcp(L.l5)), fmax(-d6 * i6, -dl6 * rcp(L.l6))));
+            L.amax = L.amax > 0.0 ? rcp(L.amax) : 1e300;
         }
     }
     if (L.role == BORDER && !APPLY) {
@@ -1253,6 +1292,23 @@ GCS_HD void phase_setup(Lane<N> &L, int lane, int wave, const VertexArgs<T> &a, 
         }
         base += d + 1;
     }
+    {
+        double *bp = slot_ptr<N>(S, SL, L.slot) + SL.BORD;
+        L.lsoc = bp; bp += D::Q;
+        L.x = bp; bp += D::N2;
+        L.W = bp; bp += D::Q * D::Q;
+        L.Wi = bp; bp += D::Q * D::Q;
+        L.W2 = bp; bp += D::Q * D::Q;
+        L.lt = bp; bp += D::Q;
+        L.soc_cv = bp; bp += N;
+        L.dba = bp; bp += D::NB;
+        L.db = bp; bp += D::NB;
+        L.dssa = bp; bp += D::Q;
+        L.dlsa = bp; bp += D::Q;
+        L.dss = bp; bp += D::Q;
+        L.dls = bp; bp += D::Q;
+        L.ksoc = bp;
+    }
     if (L.role == BORDER) {
         double *sl = slot_ptr<N>(S, SL, L.slot);
         const int p0 = a.poly_ptr[L.v];
@@ -1277,7 +1333,7 @@ GCS_HD void phase_load(Lane<N> &L, int lane, const VertexArgs<T> &a, const WaveS
                        double rho, double mu_scale)
 {
     using D = Dim<N>;
-    L.vals[0] = 0.0;
+    L.scale0 = 0.0;
     if (L.role == BLOCK) {
         const double *cen = slot_ptr<N>(S, SL, L.slot) + SL.CEN;
         double Tw[D::NW];
@@ -1301,7 +1357,7 @@ GCS_HD void phase_load(Lane<N> &L, int lane, const VertexArgs<T> &a, const WaveS
             if (L.out) sc = fmax(sc, 1.0 + fabs(rho * (L.yy * cen[k] - L.T2[k])));
         }
         sc = fmax(sc, 1.0 + fabs(rho * (L.yy - L.Ty)));
-        L.vals[0] = sc;
+        L.scale0 = sc;
     } else if (L.role == BORDER) {
 #pragma unroll
         for (int k = 0; k < D::N2; ++k) { L.p[k] = 0.0; L.x[k] = 0.0; }
@@ -1323,7 +1379,7 @@ GCS_HD void run_vertex_program(EX &ex, int wave, const VertexArgs<T> &a, const W
     ex.each([&](Lane<N> &L, int lane) { phase_setup<N, T>(L, lane, wave, a, S, SL); });
     ex.each([&](Lane<N> &L, int lane) { phase_load<N, T>(L, lane, a, S, SL, rho, mu_scale); });
     // scale of the objective gradient at the start: max over the block lanes of each group
-    ex.each([&](Lane<N> &L, int lane) { S.stage[lane] = L.role == BLOCK ? L.vals[0] : 0.0; });
+    ex.each([&](Lane<N> &L, int lane) { S.stage[lane] = L.role == BLOCK ? L.scale0 : 0.0; });
     ex.each([&](Lane<N> &L, int) {
         if (L.role == IDLE) return;
         double *sl = slot_ptr<N>(S, SL, L.slot);
@@ -1336,22 +1392,16 @@ GCS_HD void run_vertex_program(EX &ex, int wave, const VertexArgs<T> &a, const W
     });
     for (int it = 0;; ++it) {
         const int par = it & 1;
-        // ---- round 1: rows, block factorisation, sums ----
+        // ---- round 1: rows, block factorisation, sums (three chunks, each computed just before staging) ----
         ex.each([&](Lane<N> &L, int lane) {
             pass_A<N>(L, S, SL, lane, it == 0, par, rho, a.eps_edge);
-            if (L.role == BLOCK && !L.done) block_round1<N>(L, L.vals);
+            block_chunk_A<N>(L, S.stage, lane, L.role == BLOCK && !L.done);
         });
-        {
-            constexpr int C0 = 0, C1 = RED_CHUNK, C2 = 2 * RED_CHUNK;
-            constexpr int N0 = RED_CHUNK, N1 = RED_CHUNK, N2_ = D::R1_N - 2 * RED_CHUNK;
-            static_assert(N2_ > 0 && N2_ <= RED_CHUNK, "round-1 chunking assumes 2*RED_CHUNK < R1_N <= 3*RED_CHUNK");
-            ex.each([&](Lane<N> &L, int lane) { stage_write<D::R1_N, C0, N0>(L.vals, S.stage, lane, L.role == BLOCK && !L.done); });
-            ex.each([&](Lane<N> &L, int) { if (L.role != IDLE) { double *sl = slot_ptr<N>(S, SL, L.slot); stage_sum<N>(L, S.stage, sl + SL.SIN, sl + SL.SOUT, C0, N0, D::R1_RD, 2); } });
-            ex.each([&](Lane<N> &L, int lane) { stage_write<D::R1_N, C1, N1>(L.vals, S.stage, lane, L.role == BLOCK && !L.done); });
-            ex.each([&](Lane<N> &L, int) { if (L.role != IDLE) { double *sl = slot_ptr<N>(S, SL, L.slot); stage_sum<N>(L, S.stage, sl + SL.SIN, sl + SL.SOUT, C1, N1, D::R1_RD, 2); } });
-            ex.each([&](Lane<N> &L, int lane) { stage_write<D::R1_N, C2, N2_>(L.vals, S.stage, lane, L.role == BLOCK && !L.done); });
-            ex.each([&](Lane<N> &L, int) { if (L.role != IDLE) { double *sl = slot_ptr<N>(S, SL, L.slot); stage_sum<N>(L, S.stage, sl + SL.SIN, sl + SL.SOUT, C2, N2_, D::R1_RD, 2); } });
-        }
+        ex.each([&](Lane<N> &L, int) { if (L.role != IDLE) { double *sl = slot_ptr<N>(S, SL, L.slot); stage_sum<N>(L, S.stage, sl + SL.SIN, sl + SL.SOUT, 0, D::R1A_N, -1, 0); } });
+        ex.each([&](Lane<N> &L, int lane) { block_chunk_B<N>(L, S.stage, lane, L.role == BLOCK && !L.done); });
+        ex.each([&](Lane<N> &L, int) { if (L.role != IDLE) { double *sl = slot_ptr<N>(S, SL, L.slot); stage_sum<N>(L, S.stage, sl + SL.SIN, sl + SL.SOUT, D::R1_BX, D::R1B_N, -1, 0); } });
+        ex.each([&](Lane<N> &L, int lane) { block_chunk_C<N>(L, S.stage, lane, L.role == BLOCK && !L.done); });
+        ex.each([&](Lane<N> &L, int) { if (L.role != IDLE) { double *sl = slot_ptr<N>(S, SL, L.slot); stage_sum<N>(L, S.stage, sl + SL.SIN, sl + SL.SOUT, D::R1_XBX, D::R1C_N, -1, 0); } });
         // ---- border: convergence, factorisation, affine solve ----
         ex.each([&](Lane<N> &L, int) { border_factor_and_affine<N>(L, S, SL, a.ipm_tol, a.ipm_max_iter); });
         if (ex.all([&](Lane<N> &L) { return L.role == IDLE || slot_ptr<N>(S, SL, L.slot)[SL.SC + 2] != 0.0; })) break;

@@ -48,6 +48,12 @@ typedef struct {
     const double *poly_b;   /* [sum m]   (un-centred) */
     const double *center;   /* [V][n] strictly interior point of each polytope */
     int src, dst;
+    /* vertex partitions (all optional): NI = number of copy/mu columns (0 = 2E; > inc_ptr[V] adds ghost
+     * columns for the remote endpoint of cut edges), ownership masks for the five norms (NULL = all 1),
+     * and the global lengths of the reference's x / mu vectors (0 = from V, E) */
+    int NI;
+    const unsigned char *inc_counted, *edge_counted;
+    double nx_global, nmu_global;
 } oracle_graph;
 
 typedef struct {
@@ -881,7 +887,7 @@ int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double 
                        double rho, const oracle_inner_params *ip, double *copy,
                        double *xv, double *zv, double *yv, long *ipm_iters_total, int nthreads)
 {
-    const int n = G->n, c = 2 * n + 1, NI = 2 * G->E, E = G->E;
+    const int n = G->n, c = 2 * n + 1, NI = G->NI > 0 ? G->NI : 2 * G->E, E = G->E;
     int fails = 0; long iters = 0;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -915,7 +921,7 @@ int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double 
 void oracle_edge_step(const oracle_graph *G, const double *copy, double *zedge, double *mu,
                       double mu_scale, double sums[5])
 {
-    const int n = G->n, c = 2 * n + 1, NI = 2 * G->E, E = G->E;
+    const int n = G->n, c = 2 * n + 1, NI = G->NI > 0 ? G->NI : 2 * G->E, E = G->E;
     double s_r = 0, s_dz = 0, s_ax = 0, s_bz = 0, s_mu = 0;
     for (int e = 0; e < E; ++e) {
         const int it = G->edge_inc_tail[e], ih = G->edge_inc_head[e];
@@ -926,11 +932,13 @@ void oracle_edge_step(const oracle_graph *G, const double *copy, double *zedge, 
             const double mu_u = mu_scale * mu[w * NI + it] + ru, mu_w = mu_scale * mu[w * NI + ih] + rw;
             mu[w * NI + it] = mu_u; mu[w * NI + ih] = mu_w;
             zedge[w * E + e] = zn;
-            s_r += ru * ru + rw * rw;
-            s_dz += (zn - zo) * (zn - zo);
-            s_ax += cu * cu + cw * cw;
-            s_bz += zn * zn;
-            s_mu += mu_u * mu_u + mu_w * mu_w;
+            const double we = G->edge_counted ? (double)G->edge_counted[e] : 1.0;
+            const double wt = G->inc_counted ? (double)G->inc_counted[it] : 1.0, wh = G->inc_counted ? (double)G->inc_counted[ih] : 1.0;
+            s_r += wt * ru * ru + wh * rw * rw;
+            s_dz += we * (zn - zo) * (zn - zo);
+            s_ax += wt * cu * cu + wh * cw * cw;
+            s_bz += we * zn * zn;
+            s_mu += wt * mu_u * mu_u + wh * mu_w * mu_w;
         }
     }
     sums[0] = s_r; sums[1] = s_dz; sums[2] = s_ax; sums[3] = s_bz; sums[4] = s_mu;
@@ -951,7 +959,8 @@ int oracle_admm_run(const oracle_graph *G, const oracle_admm_params *ap, const o
                     double *trace, int *status_out, long *ipm_iters_total, int nthreads)
 {
     const int n = G->n;
-    const double nx = (4.0 * n + 1) * (G->V + 2.0 * G->E), nmu = (4.0 * n + 2) * G->E;
+    const double nx = G->nx_global > 0 ? G->nx_global : (4.0 * n + 1) * (G->V + 2.0 * G->E);
+    const double nmu = G->nmu_global > 0 ? G->nmu_global : (4.0 * n + 2) * G->E;
     double rho = ap->rho, mu_scale = 1.0;
     int it = 1, status = 1; /* 1 = max_it reached, 0 = converged, 2 = diverged */
     while (it <= ap->max_it) {
@@ -971,7 +980,7 @@ int oracle_admm_run(const oracle_graph *G, const oracle_admm_params *ap, const o
         it += 1;
     }
     /* a pending rescale of mu (set on the last executed iteration) is applied so the state is self-consistent */
-    if (mu_scale != 1.0) { const size_t N = (size_t)(2 * n + 1) * 2 * G->E; for (size_t i = 0; i < N; ++i) mu[i] *= mu_scale; }
+    if (mu_scale != 1.0) { const size_t N = (size_t)(2 * n + 1) * (G->NI > 0 ? G->NI : 2 * G->E); for (size_t i = 0; i < N; ++i) mu[i] *= mu_scale; }
     *status_out = status;
     return it;
 }
@@ -986,6 +995,29 @@ double oracle_compute_cost(const oracle_graph *G, const double *zv, const double
         for (int k = 0; k < n; ++k) { double dlt = zv[(size_t)v * 2 * n + k] - zv[(size_t)v * 2 * n + n + k]; s += dlt * dlt; }
         len += sqrt(s);
     }
-    for (int e = 0; e < G->E; ++e) pen += eps_edge * zedge[(size_t)(2 * n) * G->E + e];
+    for (int e = 0; e < G->E; ++e) pen += eps_edge * (G->edge_counted ? (double)G->edge_counted[e] : 1.0) * zedge[(size_t)(2 * n) * G->E + e];
     return len + pen;
+}
+
+/* one pass of the loop control (admm_solver_v3.py:697-733) on globally reduced sums; state[] = {rho, mu_scale, it, status}
+ * (status: -1 running, 0 converged, 1 max_it, 2 diverged); writes the 6-double trace record. */
+void oracle_control(const oracle_graph *G, const oracle_admm_params *ap, const double s[5], double state[4], double fails, double *tr)
+{
+    const int n = G->n;
+    const double nx = G->nx_global > 0 ? G->nx_global : (4.0 * n + 1) * (G->V + 2.0 * G->E);
+    const double nmu = G->nmu_global > 0 ? G->nmu_global : (4.0 * n + 2) * G->E;
+    double rho = state[0], mu_scale = 1.0;
+    const int it = (int)state[2];
+    if (state[3] != -1.0) return;
+    if (!isfinite(s[0] + s[1] + s[2] + s[3] + s[4])) { state[3] = 2; return; }
+    const double pri = sqrt(s[0]), dual = rho * sqrt(2.0 * s[1]);
+    if (pri >= ap->nu * dual && it < ap->it_rho_limit) { rho *= ap->tau_incr; mu_scale = 1.0 / ap->tau_incr; }
+    else if (dual >= ap->nu * pri && it < ap->it_rho_limit) { rho *= 1.0 / ap->tau_decr; mu_scale = ap->tau_incr; }
+    const double eps_pri = sqrt(nx) * ap->eps_abs + ap->eps_rel * fmax(sqrt(s[2]), sqrt(2.0 * s[3]));
+    const double eps_dual = sqrt(nmu) * ap->eps_abs + ap->eps_rel * mu_scale * sqrt(s[4]);
+    state[0] = rho; state[1] = mu_scale;
+    if (tr) { tr[0] = rho; tr[1] = pri; tr[2] = dual; tr[3] = eps_pri; tr[4] = eps_dual; tr[5] = fails; }
+    if (pri < eps_pri && dual < eps_dual) { state[3] = 0; return; }
+    state[2] = it + 1;
+    if (it + 1 > ap->max_it) state[3] = 1;
 }

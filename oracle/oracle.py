@@ -25,7 +25,9 @@ class _Graph(C.Structure):
                 ("inc_ptr", C.c_void_p), ("inc_edge", C.c_void_p), ("inc_out", C.c_void_p),
                 ("edge_inc_tail", C.c_void_p), ("edge_inc_head", C.c_void_p),
                 ("poly_ptr", C.c_void_p), ("poly_A", C.c_void_p), ("poly_b", C.c_void_p),
-                ("center", C.c_void_p), ("src", C.c_int), ("dst", C.c_int)]
+                ("center", C.c_void_p), ("src", C.c_int), ("dst", C.c_int),
+                ("NI", C.c_int), ("inc_counted", C.c_void_p), ("edge_counted", C.c_void_p),
+                ("nx_global", C.c_double), ("nmu_global", C.c_double)]
 
 
 class _Inner(C.Structure):
@@ -57,17 +59,24 @@ class Oracle:
     """One GCS instance on the CPU oracle.  State arrays are numpy float64 in the
     shared layout: copy/mu [c, 2E], zedge [c, E], xv/zv [V, 2n], yv [V]."""
 
-    def __init__(self, g, ipm_tol=1e-11, ipm_max_iter=60, eps_edge=1e-4):
+    def __init__(self, g, ipm_tol=1e-11, ipm_max_iter=60, eps_edge=1e-4, num_incidences=None, inc_counted=None,
+                 edge_counted=None, nx_global=0.0, nmu_global=0.0):
         self.g = g
         self._keep = [np.ascontiguousarray(a) for a in (
             g.edge_tail, g.edge_head, g.inc_ptr, g.inc_edge, g.inc_out, g.edge_inc_tail, g.edge_inc_head,
             g.poly_ptr, g.poly_A, g.poly_b, g.interior)]
         k = self._keep
+        self._ic = np.ascontiguousarray(inc_counted, dtype=np.uint8) if inc_counted is not None else None
+        self._ec = np.ascontiguousarray(edge_counted, dtype=np.uint8) if edge_counted is not None else None
+        self.NI = int(num_incidences) if num_incidences else 2 * g.num_edges
         self.G = _Graph(g.n, g.num_vertices, g.num_edges, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]),
-                        _p(k[5]), _p(k[6]), _p(k[7]), _p(k[8]), _p(k[9]), _p(k[10]), g.src, g.dst)
+                        _p(k[5]), _p(k[6]), _p(k[7]), _p(k[8]), _p(k[9]), _p(k[10]), g.src, g.dst,
+                        int(num_incidences or 0),
+                        _p(self._ic) if self._ic is not None else None, _p(self._ec) if self._ec is not None else None,
+                        float(nx_global), float(nmu_global))
         self.inner = _Inner(eps_edge, ipm_tol, ipm_max_iter)
         c, E, V, n = g.c, g.num_edges, g.num_vertices, g.n
-        self.zedge = np.zeros((c, E)); self.mu = np.zeros((c, 2 * E)); self.copy = np.zeros((c, 2 * E))
+        self.zedge = np.zeros((c, E)); self.mu = np.zeros((c, self.NI)); self.copy = np.zeros((c, self.NI))
         self.xv = np.zeros((V, 2 * n)); self.zv = np.zeros((V, 2 * n)); self.yv = np.zeros(V)
         self.ipm_iters = C.c_long(0)
 
@@ -96,3 +105,12 @@ class Oracle:
 
     def cost(self):
         return lib().oracle_compute_cost(C.byref(self.G), _p(self.zv), _p(self.zedge), C.c_double(self.inner.eps_edge))
+
+    def control(self, ap, sums, state, fails=0.0, trace_row=None):
+        """loop control on (globally reduced) sums; state = np.array([rho, mu_scale, it, status])"""
+        lib().oracle_control(C.byref(self.G), C.byref(ap), _p(np.ascontiguousarray(sums, dtype=np.float64)), _p(state),
+                             C.c_double(fails), _p(trace_row) if trace_row is not None else None)
+
+
+def admm_params(rho=1.0, tau=2.0, nu=10.0, it_rho_limit=100, eps_abs=1e-4, eps_rel=1e-3, max_it=1000):
+    return _Admm(rho, tau, tau, nu, it_rho_limit, eps_abs, eps_rel, max_it)

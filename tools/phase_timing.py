@@ -1,0 +1,26 @@
+"""Diagnostic: share of wave cycles per barrier-separated phase of the vertex kernel (needs the\n-DGCS_PHASE_TIMING build: hipcc ... -DGCS_PHASE_TIMING -o gcs_admm_amd/libgcsadmm_timing.so).  Read its SHARES, not its length."""
+import sys, os, ctypes as C, numpy as np
+sys.path.insert(0, os.getcwd())
+import torch
+from gcs_admm_amd import solver
+solver.LIB_PATH = os.path.join(os.getcwd(), "gcs_admm_amd", "libgcsadmm_timing.so")
+from gcs_admm_amd.graph import lattice_boxes
+from gcs_admm_amd.cases import load_fixture
+names = ["setup", "load", "scale:stage", "scale:sum", "scale:read",
+         "passA+blockfactor+chunkA", "sumA", "chunkB", "sumB", "chunkC", "sumC", "border_factor+affine", "passB", "sumR2",
+         "border_sigma", "corr_rhs", "sumR3", "border_corr_solve", "passD", "sumR4", "border_alpha", "update(passE)"]
+for wl in ("s10k", "benchmark4"):
+    g = lattice_boxes(100, 100, seed=0) if wl == "s10k" else load_fixture("benchmark4")[1]
+    d = solver.DeviceSolver(g, "f64", device=0)
+    d.reset(max_it=1000, eps_abs=0.0, eps_rel=0.0)
+    d.enqueue(20)
+    torch.cuda.synchronize()
+    out = (C.c_ulonglong * 64)()
+    before = np.zeros(64)
+    d.lib.gcsadmm_debug_phase_cycles(out); before = np.array(list(out), dtype=np.float64)
+    d.enqueue(20); torch.cuda.synchronize()
+    d.lib.gcsadmm_debug_phase_cycles(out); cyc = np.array(list(out), dtype=np.float64) - before
+    tot = cyc.sum()
+    print(wl, "total wave-cycles (s_memtime ticks) over 20 steps: %.3e" % tot)
+    for i, n in enumerate(names):
+        print("  %-28s %6.2f %%" % (n, 100 * cyc[i] / tot))
