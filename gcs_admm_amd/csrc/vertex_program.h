@@ -644,12 +644,27 @@ GCS_HD void stage_sum(const Lane<N> &L, const double *stage, double *sin, double
     for (int k = L.glane; k < cnt; k += gsize) {
         const double *row = stage + k * WAVE + L.gbase;
         const bool sp = (base + k == special);
-        double a, b;
-        if (sp && op == 1) { a = 1e300; b = 1e300; } else { a = 0; b = 0; }
-        for (int l = 1; l <= L.d_in; ++l) a = sp ? (op == 1 ? fmin(a, row[l]) : fmax(a, row[l])) : a + row[l];
-        for (int l = L.d_in + 1; l <= L.d; ++l) b = sp ? (op == 1 ? fmin(b, row[l]) : fmax(b, row[l])) : b + row[l];
-        sin[base + k] = a;
-        sout[base + k] = b;
+        const double ident = (sp && op == 1) ? 1e300 : ((sp && op == 2) ? -1e300 : 0.0);
+        // four loads in flight per wait: the lanes of a side are read in groups of four, out-of-range
+        // slots re-read the last valid lane and contribute the identity
+        auto side = [&](int lo, int hi) -> double {
+            double acc = ident;
+            for (int l = lo; l <= hi; l += 4) {
+                double v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = l + j <= hi ? l + j : hi;
+                    const double x = row[idx];
+                    v[j] = l + j <= hi ? x : ident;
+                }
+                if (sp && op == 1) acc = fmin(acc, fmin(fmin(v[0], v[1]), fmin(v[2], v[3])));
+                else if (sp && op == 2) acc = fmax(acc, fmax(fmax(v[0], v[1]), fmax(v[2], v[3])));
+                else acc += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            return acc;
+        };
+        sin[base + k] = side(1, L.d_in);
+        sout[base + k] = side(L.d_in + 1, L.d);
     }
 }
 
@@ -830,7 +845,7 @@ GCS_HD void border_factor_and_affine(Lane<N> &L, const WaveShared &S, const Slot
             }
     }
     // ---- reduced border matrix M (packed lower, order x1 x2 z1 z2 yv), assembled entry by entry in LDS ----
-    double *M = sl + SL.MF;
+    double M[D::NBS];      // in registers: the LDS-resident variant costs ~3x (one LDS instruction per operand)
     const double *Y0 = sl + SL.YS, *Y1 = sl + SL.YS + D::NW * D::N2;
     const double *BX0 = sl + SL.BXS, *BX1 = sl + SL.BXS + D::NW * D::N2;
     const double *Bi0 = sl + SL.BSI, *Bi1 = sl + SL.BSI + D::NWS;
@@ -901,7 +916,9 @@ GCS_HD void border_factor_and_affine(Lane<N> &L, const WaveShared &S, const Slot
         for (int k = 0; k < N; ++k)
 #pragma unroll
             for (int l = 0; l <= k; ++l) M[PK(BI::Z1 + k, BI::Z1 + l)] += Su[k * N + l];
-        chol_lds<D::NB1>(M);
+        chol_packed<D::NB1>(M);
+#pragma unroll
+        for (int k = 0; k < D::NBS; ++k) sl[SL.MF + k] = M[k];
     }
     // ---- affine direction (kappa = 0) ----
     double gb[D::NB];

@@ -422,6 +422,14 @@ static void project_simplex(int d, const double *v, double *out)
  * Tz: targets [c][d] (word-major, local incidence order): zu[n], zw[n], y.
  * out: copies [c][d] in the same layout, xv[2n], zv[2n], yv.  Returns iterations (<0: not converged). */
 static __thread int dbg_vertex = -1;
+/* per-thread workspace, grown on demand and reused across solves (no allocation in the hot loop) */
+static __thread char *ws_buf = NULL;
+static __thread size_t ws_cap = 0;
+static void *ws_get(size_t bytes)
+{
+    if (bytes > ws_cap) { free(ws_buf); ws_cap = bytes + bytes / 2 + 4096; ws_buf = (char *)malloc(ws_cap); }
+    return ws_buf;
+}
 int oracle_solve_vertex(int n, int m, const double *A, const double *b_raw, const double *cen,
                         int d, int d_in, int is_src, int is_dst, const double *T, double rho,
                         const oracle_inner_params *ip, double *copy, double *xv, double *zv, double *yv)
@@ -474,14 +482,20 @@ int oracle_solve_vertex(int n, int m, const double *A, const double *b_raw, cons
     /* ---- generic vertex: primal-dual interior point on the centred arrow form ---- */
     vtx_t P; fact_t F;
     P.n = n; P.m = m; P.d = d; P.d_in = d_in; P.A = A; P.cen = cen; P.rho = rho; P.eps_edge = ip->eps_edge;
-    double *bc = (double *)malloc(sizeof(double) * m);
+    const int R = 2 * m;
+    const size_t n_pool = (size_t)(6 * R) + (size_t)d * 6 * R, n_ds = (size_t)4 * R + (size_t)d * 4 * R;
+    const size_t off_pool = ((size_t)m * sizeof(double) + 63) & ~(size_t)63;
+    const size_t off_ds = (off_pool + n_pool * sizeof(double) + 63) & ~(size_t)63;
+    const size_t off_blk = (off_ds + n_ds * sizeof(double) + 63) & ~(size_t)63;
+    char *ws = (char *)ws_get(off_blk + (size_t)d * sizeof(block_t));
+    double *bc = (double *)ws;
     for (int j = 0; j < m; ++j) { double s = b_raw[j]; for (int k = 0; k < n; ++k) s -= A[j * n + k] * cen[k]; bc[j] = s; }
     P.b = bc;
-    const int R = 2 * m;
-    double *pool = (double *)calloc((size_t)(6 * R) + (size_t)d * 6 * R, sizeof(double));
+    double *pool = (double *)(ws + off_pool);
+    memset(pool, 0, n_pool * sizeof(double));
     P.l1 = pool; P.l2 = pool + R; P.s1 = pool + 2 * R; P.s2 = pool + 3 * R; P.k1 = pool + 4 * R; P.k2 = pool + 5 * R;
-    P.blk = (block_t *)calloc(d, sizeof(block_t));
-    double *ds1 = (double *)calloc((size_t)4 * R + (size_t)d * 4 * R, sizeof(double));
+    P.blk = (block_t *)(ws + off_blk);
+    double *ds1 = (double *)(ws + off_ds);
     double *ds2 = ds1 + R, *dl1 = ds1 + 2 * R, *dl2 = ds1 + 3 * R;
     for (int e = 0; e < d; ++e) {
         block_t *B = &P.blk[e];
@@ -871,7 +885,6 @@ int oracle_solve_vertex(int n, int m, const double *A, const double *b_raw, cons
         }
         CW(2 * n, e) = B->y;
     }
-    free(bc); free(pool); free(P.blk); free(ds1);
     (void)c;
     return status == 0 ? it : -(100 + it);
 #undef TW
@@ -891,13 +904,14 @@ int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double 
     int fails = 0; long iters = 0;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
-#pragma omp parallel for schedule(dynamic, 8) reduction(+ : fails, iters)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : fails, iters)
 #endif
     for (int v = 0; v < G->V; ++v) {
         const int lo = G->inc_ptr[v], d = G->inc_ptr[v + 1] - lo;
         int d_in = 0;
         for (int k = 0; k < d; ++k) d_in += !G->inc_out[lo + k];
-        double *T = (double *)malloc(sizeof(double) * 2 * c * (d > 0 ? d : 1)), *C = T + c * (d > 0 ? d : 1);
+        double Tst[2 * MAXNW * 64];
+        double *T = (d <= 64) ? Tst : (double *)malloc(sizeof(double) * 2 * c * d), *C = T + c * (d > 0 ? d : 1);
         for (int k = 0; k < d; ++k) {
             const int e = G->inc_edge[lo + k];
             for (int w = 0; w < c; ++w) T[w * d + k] = zedge[w * E + e] - mu_scale * mu[w * NI + lo + k];
@@ -910,7 +924,7 @@ int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double 
         if (r < 0) fails += 1; else iters += r;
         for (int k = 0; k < d; ++k)
             for (int w = 0; w < c; ++w) copy[w * NI + lo + k] = C[w * d + k];
-        free(T);
+        if (T != Tst) free(T);
     }
     if (ipm_iters_total) *ipm_iters_total += iters;
     return fails;
