@@ -333,6 +333,10 @@ template <int N> GCS_HD double *slot_ptr(const WaveShared &S, const SlotLayout<N
 template <int N, int I, class F>
 GCS_HD void rows_half(const Lane<N> &L, const double *A, const double *bc, const double *x, F &&f)
 {
+    double xi[N];   // loop invariant: read once (the stores of the passes could alias it for the compiler)
+#pragma unroll
+    for (int k = 0; k < N; ++k) xi[k] = x[I * N + k];
+#pragma unroll 2
     for (int j = 0; j < L.m; ++j) {
         double a[N];
 #pragma unroll
@@ -340,7 +344,7 @@ GCS_HD void rows_half(const Lane<N> &L, const double *A, const double *bc, const
         const double b = bc[j];
         double ap = 0, ax = 0;
 #pragma unroll
-        for (int k = 0; k < N; ++k) { ap += a[k] * L.p[I * N + k]; ax += a[k] * x[I * N + k]; }
+        for (int k = 0; k < N; ++k) { ap += a[k] * L.p[I * N + k]; ax += a[k] * xi[k]; }
         const double sa = b * L.yy - ap;
         const double sb = b * (1.0 - L.yy) - (ax - ap);
         f(j, a, b, sa, sb);
