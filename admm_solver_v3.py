@@ -76,7 +76,9 @@ def main(argv=None):
     print("===============================================================")
     print("POST-ROUNDING")
     print("===============================================================")
-    x_v_rounded = y_v_rounded = None      # rounding + convex restriction: SURVEY.md section 8(f) "next"
+    from gcs_admm_amd.rounding import rounding
+    I_v_out = {v: [e for e in E if e[0] == v] for v in V}
+    final_cost, x_v_rounded, y_v_rounded = rounding(y_e_e_sol, V, E, I_v_out, As, bs, n)   # N=5, M=20 (:759)
     print(f"{x_v_rounded=}\n")
     print(f"{y_v_rounded=}\n")
     if args.show_plot == True:  # noqa: E712  (string semantics on purpose)

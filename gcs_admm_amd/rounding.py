@@ -1,0 +1,130 @@
+"""Rounding of the relaxed edge activations to an s-t path and the convex restriction along it --
+the step that follows the ADMM loop in the reference (GCS_utils.py:92-181 ``rounding``,
+:17-89 ``solve_convex_restriction``; called at admm_solver_v3.py:759 with N=5, M=20, the case file's
+own N, M being ignored -- quirk Q5).  SURVEY.md section 8(f) item 1; runs once, on the host.
+
+Differences from the reference, on purpose: the random walk is seeded (the reference draws from the
+unseeded global numpy generator, GCS_utils.py:131, so its runs are not reproducible), and the
+restriction is solved by this repo's own small SOCP solver (gcs_admm_amd/conic.py) on the polyline
+form: along a fixed path the continuity constraints x_{v,2} = x_{w,1} make the unknowns a chain of
+points q_0 .. q_{k+1} with q_j, q_{j+1} in P_{v_j}, and the cost is the polyline length.
+"""
+from __future__ import annotations
+
+from typing import Dict, Hashable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .conic import solve_socp
+from .graph import chebyshev_center
+
+
+def find_path_via_random_dfs(y_e: Dict[Tuple[Hashable, Hashable], float], I_v_out, rng) -> Optional[List[Hashable]]:
+    """Depth-first walk from 's' choosing the next out-edge with probability proportional to y_e
+    (edges with y_e <= 1e-15 and visited heads excluded), one draw per node, dead end -> back out
+    (GCS_utils.py:109-146: a node whose single draw fails is abandoned, not retried)."""
+    path, visited = ['s'], {'s'}
+
+    def dfs(cur):
+        if cur == 't':
+            return True
+        edges = [e for e in I_v_out.get(cur, []) if e[1] not in visited and y_e.get(e, 0) > 1e-15]
+        if not edges:
+            return False
+        probs = np.array([y_e[e] for e in edges], dtype=float)
+        tot = probs.sum()
+        if tot < 1e-15:
+            return False
+        idx = int(np.searchsorted(np.cumsum(probs / tot), rng.random()))
+        idx = min(idx, len(edges) - 1)
+        nxt = edges[idx][1]
+        visited.add(nxt); path.append(nxt)
+        if dfs(nxt):
+            return True
+        visited.remove(nxt); path.pop()
+        return False
+
+    return path if dfs('s') else None
+
+
+def solve_path_restriction(As, bs, n: int, path: Sequence[Hashable]):
+    """Shortest polyline through the regions of ``path`` in order.  Returns (cost, {v: x_v (2n)})
+    or (inf, None) when consecutive regions do not intersect."""
+    k = len(path)
+    # point j lies in P_{path[j-1]} and P_{path[j]} (ends: only one region)
+    regions = [[path[0]]] + [[path[j - 1], path[j]] for j in range(1, k)] + [[path[-1]]]
+    npts = k + 1
+    q0 = []
+    for reg in regions:
+        A = np.vstack([np.asarray(As[v], float) for v in reg]); b = np.hstack([np.asarray(bs[v], float) for v in reg])
+        try:
+            q0.append(chebyshev_center(A, b))
+        except ValueError:
+            return float('inf'), None
+    nseg = npts - 1
+    nw = npts * n + nseg                       # points, then one epigraph variable per segment
+    c = np.zeros(nw); c[npts * n:] = 1.0
+    rows, rhs = [], []
+    for j, reg in enumerate(regions):
+        for v in reg:
+            A = np.asarray(As[v], float); b = np.asarray(bs[v], float)
+            for r in range(A.shape[0]):
+                row = np.zeros(nw); row[j * n:(j + 1) * n] = A[r]
+                rows.append(row); rhs.append(b[r])
+    p = len(rows)
+    for sgm in range(nseg):                    # cone: (t_s, q_{s+1} - q_s)
+        row = np.zeros(nw); row[npts * n + sgm] = -1.0
+        rows.append(row); rhs.append(0.0)
+        for d in range(n):
+            row = np.zeros(nw); row[(sgm + 1) * n + d] = -1.0; row[sgm * n + d] = 1.0
+            rows.append(row); rhs.append(0.0)
+    w0 = np.concatenate([np.concatenate(q0)] + [[np.linalg.norm(q0[s + 1] - q0[s]) + 1.0] for s in range(nseg)])
+    w, val, _ = solve_socp(c, np.array(rows), np.array(rhs), p, [n + 1] * nseg, w0)
+    q = w[:npts * n].reshape(npts, n)
+    cost = float(sum(np.linalg.norm(q[s + 1] - q[s]) for s in range(nseg)))
+    return cost, {v: np.concatenate([q[j], q[j + 1]]) for j, v in enumerate(path)}
+
+
+def most_probable_path(y_e, I_v_out) -> Optional[List[Hashable]]:
+    """Deterministic walk that always takes the out-edge with the largest activation."""
+    path, visited, cur = ['s'], {'s'}, 's'
+    while cur != 't':
+        cand = [(y_e.get(e, 0.0), k) for k, e in enumerate(I_v_out.get(cur, [])) if e[1] not in visited and y_e.get(e, 0) > 1e-15]
+        if not cand:
+            return None
+        cur = I_v_out[cur][max(cand)[1]][1]
+        visited.add(cur); path.append(cur)
+    return path
+
+
+def rounding(y_e_sol, V, E, I_v_out, As, bs, n, N=5, M=20, seed=0):
+    """Up to M seeded random walks, at most N distinct paths, best restricted cost wins
+    (GCS_utils.py:148-181); the deterministic most-probable path is tried first (an addition: it
+    removes most of the run-to-run variation the reference's unseeded sampling has).  Returns
+    (cost, x_v_rounded, y_v_rounded) with the reference's shapes: every vertex has an entry;
+    off-path vertices get x = 0, y = 0."""
+    rng = np.random.default_rng(seed)
+    seen, cands = set(), []
+    first = most_probable_path(y_e_sol, I_v_out)
+    if first is not None:
+        seen.add(tuple(first))
+        cost, xs = solve_path_restriction(As, bs, n, first)
+        if xs is not None:
+            cands.append((cost, first, xs))
+    for _ in range(M):
+        if len(cands) >= N:
+            break
+        pth = find_path_via_random_dfs(y_e_sol, I_v_out, rng)
+        if pth is None or tuple(pth) in seen:
+            continue
+        seen.add(tuple(pth))
+        cost, xs = solve_path_restriction(As, bs, n, pth)
+        if xs is not None:
+            cands.append((cost, pth, xs))
+    if not cands:
+        print("Rounding failed to find any feasible paths.")
+        return float('inf'), None, None
+    cost, pth, xs = min(cands, key=lambda t: t[0])
+    x_v = {v: xs.get(v, np.zeros(2 * n)) for v in V}
+    y_v = {v: (1 if v in xs else 0) for v in V}
+    return cost, x_v, y_v
