@@ -35,8 +35,8 @@ constexpr int MAX_SPECIAL_DEG = 256;
 __device__ unsigned long long g_phase_cycles[64];
 #endif
 
-template <int N> struct GpuExec {
-    Lane<N> &L;
+template <class LaneT> struct GpuExec {
+    LaneT &L;
     int lane;
 #ifdef GCS_PHASE_TIMING
     // diagnostic build only: cycles per barrier-separated phase, summed over wavefronts
@@ -66,28 +66,54 @@ template <int N> struct GpuExec {
     }
 };
 
-template <int N, class T>
-__global__ __launch_bounds__(WAVE) void vertex_kernel(VertexArgs<T> a, const gcsadmm_control_block *cb)
+// the two instantiations of the wavefront program (vertex_program.h)
+struct ProgGeneric {   // any facet count per polytope, facet-row duals in LDS
+    template <int N> using LaneT = gcs::Lane<N>;
+    template <class T> using Args = gcs::VertexArgs<T>;
+    using Shared = gcs::WaveShared;
+    static constexpr bool lds_duals = true;
+    template <int N, class T, class EX>
+    static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
+    {
+        gcs::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
+    }
+};
+struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet loops, row duals in registers
+    template <int N> using LaneT = gcs_m4::Lane<N>;
+    template <class T> using Args = gcs_m4::VertexArgs<T>;
+    using Shared = gcs_m4::WaveShared;
+    static constexpr bool lds_duals = false;
+    template <int N, class T, class EX>
+    static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
+    {
+        gcs_m4::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
+    }
+};
+
+template <class PROG, int N, class T>
+__global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Args<T> a, const gcsadmm_control_block *cb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (cb->status != GCSADMM_RUNNING) return;
     const double rho = cb->rho, mu_scale = cb->mu_scale;
-    WaveShared S;
+    typename PROG::Shared S;
     S.MM = a.MM;
+    const int dual_rows = PROG::lds_duals ? 2 * a.MM : 0;
     S.lamA = smem;
-    S.lamB = S.lamA + 2 * a.MM * WAVE;
-    S.stage = S.lamB + 2 * a.MM * WAVE;
+    S.lamB = S.lamA + dual_rows * WAVE;
+    S.stage = S.lamB + dual_rows * WAVE;
     S.slots = S.stage + RED_CHUNK * WAVE;
-    Lane<N> L;
+    using LaneT = typename PROG::template LaneT<N>;
+    LaneT L;
 #ifdef GCS_PHASE_TIMING
     __shared__ unsigned long long acc[64];
     if (threadIdx.x < 64) acc[threadIdx.x] = 0;
     __syncthreads();
-    GpuExec<N> ex{L, (int)threadIdx.x, 0, acc};
+    GpuExec<LaneT> ex{L, (int)threadIdx.x, 0, acc};
 #else
-    GpuExec<N> ex{L, (int)threadIdx.x};
+    GpuExec<LaneT> ex{L, (int)threadIdx.x};
 #endif
-    run_vertex_program<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
+    PROG::template run<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
 #ifdef GCS_PHASE_TIMING
     __syncthreads();
     if (threadIdx.x < 64) atomicAdd(&g_phase_cycles[threadIdx.x], acc[threadIdx.x]);
@@ -335,6 +361,7 @@ __global__ __launch_bounds__(256) void cost_kernel(int V, int E, int n, const do
 struct gcsadmm_handle_s {
     int n = 0, V = 0, E = 0, NI = 0, NI_owned = 0, c = 0, MM = 0, dtype = 0, device = 0;
     int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
+    bool all_m4 = false;      // every generic vertex has exactly 4 facets -> the register-dual program
     double nx = 0, nmu = 0;
     gcsadmm_params params{};
     bool params_set = false;
@@ -372,18 +399,24 @@ template <class U> static hipError_t upload(U **dst, const U *src, size_t count)
     return hipMemset(*dst, 0, count * sizeof(U));
 }
 
+template <class PROG, class T> static void launch_vertex_prog(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
+{
+    typename PROG::template Args<T> a;
+    a.n_waves = h->n_waves; a.wave_slot_ptr = h->d_wave_slot_ptr; a.wave_vtx = h->d_wave_vtx;
+    a.inc_ptr = h->d_inc_ptr; a.deg_in = h->d_deg_in; a.inc_edge = h->d_inc_edge; a.poly_ptr = h->d_poly_ptr;
+    a.poly_A = h->d_poly_A; a.poly_bc = h->d_poly_bc; a.center = h->d_center;
+    a.E = h->E; a.NI = h->NI; a.MM = h->MM;
+    a.zedge = (const T *)st->zedge; a.mu = (const T *)st->mu; a.copy = (T *)st->copy;
+    a.xv = st->xv; a.zv = st->zv; a.yv = st->yv; a.counters = h->d_counters;
+    a.eps_edge = h->params.eps_edge; a.ipm_tol = h->params.ipm_tol; a.ipm_max_iter = h->params.ipm_max_iter;
+    hipLaunchKernelGGL((vertex_kernel<PROG, 2, T>), dim3(h->n_waves), dim3(WAVE), h->lds_bytes, s, a, h->d_cb);
+}
+
 template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
 {
     if (h->n_waves > 0) {
-        VertexArgs<T> a;
-        a.n_waves = h->n_waves; a.wave_slot_ptr = h->d_wave_slot_ptr; a.wave_vtx = h->d_wave_vtx;
-        a.inc_ptr = h->d_inc_ptr; a.deg_in = h->d_deg_in; a.inc_edge = h->d_inc_edge; a.poly_ptr = h->d_poly_ptr;
-        a.poly_A = h->d_poly_A; a.poly_bc = h->d_poly_bc; a.center = h->d_center;
-        a.E = h->E; a.NI = h->NI; a.MM = h->MM;
-        a.zedge = (const T *)st->zedge; a.mu = (const T *)st->mu; a.copy = (T *)st->copy;
-        a.xv = st->xv; a.zv = st->zv; a.yv = st->yv; a.counters = h->d_counters;
-        a.eps_edge = h->params.eps_edge; a.ipm_tol = h->params.ipm_tol; a.ipm_max_iter = h->params.ipm_max_iter;
-        hipLaunchKernelGGL((vertex_kernel<2, T>), dim3(h->n_waves), dim3(WAVE), h->lds_bytes, s, a, h->d_cb);
+        if (h->all_m4) launch_vertex_prog<ProgM4, T>(h, st, s);
+        else launch_vertex_prog<ProgGeneric, T>(h, st, s);
     }
     if (h->n_special > 0) {
         SpecialArgs<T> a;
@@ -485,9 +518,16 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
 
     // classify vertices and pack the generic ones into wavefronts: d+1 lanes each
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx;
+    bool all_m4 = true;
+    for (int v = 0; v < V; ++v) {
+        const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
+        const bool generic = !(v == g->src || v == g->dst || din == 0 || d - din == 0);
+        if (generic && g->poly_ptr[v + 1] - g->poly_ptr[v] != 4) all_m4 = false;
+    }
+    auto lds_need = [&](int slots) { return (size_t)(all_m4 ? gcs_m4::lds_doubles(n, MM, slots) : gcs::lds_doubles(n, MM, slots)) * 8; };
     int slots_cap = MAX_SLOTS;
-    while (slots_cap > 1 && (size_t)lds_doubles(n, MM, slots_cap) * 8 > 160 * 1024) --slots_cap;
-    if ((size_t)lds_doubles(n, MM, slots_cap) * 8 > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
+    while (slots_cap > 1 && lds_need(slots_cap) > 160 * 1024) --slots_cap;
+    if (lds_need(slots_cap) > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
     int lanes = 0, slots = 0, max_slots_used = 0;
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
@@ -515,7 +555,8 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     h->dtype = g->state_dtype; h->device = g->device;
     h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
     h->slots_cap = std::max(1, max_slots_used);
-    h->lds_bytes = lds_doubles(n, MM, h->slots_cap) * 8;
+    h->all_m4 = all_m4;
+    h->lds_bytes = (int)lds_need(h->slots_cap);
     h->nx = g->nx_global > 0 ? g->nx_global : (4.0 * n + 1) * (V + 2.0 * E);
     h->nmu = g->nmu_global > 0 ? g->nmu_global : (4.0 * n + 2) * E;
     h->edge_blocks = std::max(1, std::min((E + EDGE_BLOCK - 1) / EDGE_BLOCK, 2048));
@@ -548,8 +589,9 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_sums, (const double *)nullptr, 5);
 #undef UP
     if (h->lds_bytes > 48 * 1024) {
-        if (h->dtype == GCSADMM_F64) e = hipFuncSetAttribute((const void *)vertex_kernel<2, double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-        else e = hipFuncSetAttribute((const void *)vertex_kernel<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+        const void *fn = h->all_m4 ? (h->dtype == GCSADMM_F64 ? (const void *)vertex_kernel<ProgM4, 2, double> : (const void *)vertex_kernel<ProgM4, 2, float>)
+                                   : (h->dtype == GCSADMM_F64 ? (const void *)vertex_kernel<ProgGeneric, 2, double> : (const void *)vertex_kernel<ProgGeneric, 2, float>);
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
         if (e != hipSuccess) return bail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     *out = h;

@@ -8,7 +8,12 @@
 
 #include "vertex_program.h"
 
+
+// the program exists in two instantiations (vertex_program.h); emulate both
+#define EMU_NAME emu_vertex_step
+namespace emu_generic {
 using namespace gcs;
+
 
 template <int N> struct CpuExec {
     Lane<N> Ls[WAVE];
@@ -17,7 +22,7 @@ template <int N> struct CpuExec {
     void count(int *c, int fails, int iters) { c[0] += fails; c[1] += iters; }
 };
 
-extern "C" int emu_vertex_step(int n, int V, int E, int NI, const int *inc_ptr, const int *inc_edge, const int *inc_out,
+extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const int *inc_edge, const int *inc_out,
                                const int *poly_ptr, const double *poly_A, const double *poly_b, const double *center,
                                int src, int dst, const double *zedge, const double *mu, double rho, double mu_scale,
                                double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv, double *zv,
@@ -60,10 +65,79 @@ extern "C" int emu_vertex_step(int n, int V, int E, int NI, const int *inc_ptr, 
     for (int w = 0; w < n_waves; ++w) {
         std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
         WaveShared S;
-        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + 2 * MM * WAVE; S.stage = S.lamB + 2 * MM * WAVE;
+        const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
+        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE; S.stage = S.lamB + dual_rows * WAVE;
         S.slots = S.stage + RED_CHUNK * WAVE;
         run_vertex_program<2, double>(*ex, w, a, S, rho, mu_scale);
     }
     delete ex;
     return 0;
 }
+
+} // namespace emu_generic
+#undef EMU_NAME
+#define EMU_NAME emu_vertex_step_m4
+namespace emu_m4 {
+using namespace gcs_m4;
+
+
+template <int N> struct CpuExec {
+    Lane<N> Ls[WAVE];
+    template <class F> void each(F &&f) { for (int l = 0; l < WAVE; ++l) f(Ls[l], l); }
+    template <class P> bool all(P &&p) { for (int l = 0; l < WAVE; ++l) if (!p(Ls[l])) return false; return true; }
+    void count(int *c, int fails, int iters) { c[0] += fails; c[1] += iters; }
+};
+
+extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const int *inc_edge, const int *inc_out,
+                               const int *poly_ptr, const double *poly_A, const double *poly_b, const double *center,
+                               int src, int dst, const double *zedge, const double *mu, double rho, double mu_scale,
+                               double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv, double *zv,
+                               double *yv, int *counters, int *is_generic)
+{
+    if (n != 2) return 1;
+    std::vector<int> deg_in(V, 0);
+    int MM = 1;
+    for (int v = 0; v < V; ++v) {
+        for (int k = inc_ptr[v]; k < inc_ptr[v + 1]; ++k) deg_in[v] += !inc_out[k];
+        MM = std::max(MM, poly_ptr[v + 1] - poly_ptr[v]);
+    }
+    std::vector<double> bc(poly_ptr[V]);
+    for (int v = 0; v < V; ++v)
+        for (int j = poly_ptr[v]; j < poly_ptr[v + 1]; ++j) {
+            double s = poly_b[j];
+            for (int k = 0; k < n; ++k) s -= poly_A[(size_t)j * n + k] * center[(size_t)v * n + k];
+            bc[j] = s;
+        }
+    std::vector<int> wave_slot_ptr{0}, wave_vtx;
+    int lanes = 0, slots = 0;
+    for (int v = 0; v < V; ++v) {
+        const int d = inc_ptr[v + 1] - inc_ptr[v], din = deg_in[v];
+        is_generic[v] = !(v == src || v == dst || din == 0 || d - din == 0);
+        if (!is_generic[v]) continue;
+        if (d + 1 > WAVE) return 2;
+        if (lanes + d + 1 > WAVE || slots + 1 > MAX_SLOTS) { wave_slot_ptr.push_back((int)wave_vtx.size()); lanes = 0; slots = 0; }
+        wave_vtx.push_back(v); lanes += d + 1; slots += 1;
+    }
+    if ((int)wave_vtx.size() > wave_slot_ptr.back()) wave_slot_ptr.push_back((int)wave_vtx.size());
+    const int n_waves = (int)wave_slot_ptr.size() - 1;
+    VertexArgs<double> a;
+    a.n_waves = n_waves; a.wave_slot_ptr = wave_slot_ptr.data(); a.wave_vtx = wave_vtx.data();
+    a.inc_ptr = inc_ptr; a.deg_in = deg_in.data(); a.inc_edge = inc_edge; a.poly_ptr = poly_ptr;
+    a.poly_A = poly_A; a.poly_bc = bc.data(); a.center = center; a.E = E; a.NI = NI; a.MM = MM;
+    a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
+    a.eps_edge = eps_edge; a.ipm_tol = ipm_tol; a.ipm_max_iter = ipm_max_iter;
+    std::vector<double> smem(lds_doubles(n, MM, MAX_SLOTS));
+    auto *ex = new CpuExec<2>();
+    for (int w = 0; w < n_waves; ++w) {
+        std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
+        WaveShared S;
+        const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
+        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE; S.stage = S.lamB + dual_rows * WAVE;
+        S.slots = S.stage + RED_CHUNK * WAVE;
+        run_vertex_program<2, double>(*ex, w, a, S, rho, mu_scale);
+    }
+    delete ex;
+    return 0;
+}
+
+} // namespace emu_m4

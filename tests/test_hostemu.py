@@ -34,11 +34,11 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def emu_step(lib, g, zedge, mu, rho, mu_scale):
+def emu_step(lib, g, zedge, mu, rho, mu_scale, fn="emu_vertex_step"):
     c, NI, V = g.c, 2 * g.num_edges, g.num_vertices
     copy = np.zeros((c, NI)); xv = np.zeros((V, 2 * g.n)); zv = np.zeros_like(xv); yv = np.zeros(V)
     cnt = np.zeros(2, dtype=np.int32); gen = np.zeros(V, dtype=np.int32)
-    r = lib.emu_vertex_step(g.n, V, g.num_edges, NI, _p(g.inc_ptr), _p(g.inc_edge), _p(g.inc_out), _p(g.poly_ptr),
+    r = getattr(lib, fn)(g.n, V, g.num_edges, NI, _p(g.inc_ptr), _p(g.inc_edge), _p(g.inc_out), _p(g.poly_ptr),
                             _p(g.poly_A), _p(g.poly_b), _p(g.interior), g.src, g.dst, _p(zedge), _p(mu),
                             C.c_double(rho), C.c_double(mu_scale), C.c_double(1e-4), C.c_double(1e-9), 60,
                             _p(copy), _p(xv), _p(zv), _p(yv), _p(cnt), _p(gen))
@@ -64,3 +64,22 @@ def test_emulated_wave_program_matches_oracle(emu, oracle_lib, name, steps):
         o.edge_step(1.0)
     diffs = np.array(diffs)
     assert diffs.max() <= 2e-3 and np.median(diffs) <= 1e-5
+
+
+def test_fixed_facet_variant_equals_generic(emu, oracle_lib):
+    """vertex_program.h instantiates the program twice (any facet count / exactly 4 facets with the row
+    duals in registers); on a graph of boxes both must produce the same numbers."""
+    from gcs_admm_amd.graph import lattice_boxes
+    g = lattice_boxes(7, 6, seed=2)
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    for it in range(12):
+        z0, m0 = o.zedge.copy(), o.mu.copy()
+        a = emu_step(emu, g, z0, m0, 1.0, 1.0)
+        b = emu_step(emu, g, z0, m0, 1.0, 1.0, fn="emu_vertex_step_m4")
+        gen = a[5] == 1
+        mask = np.zeros(2 * g.num_edges, bool)
+        for v in np.nonzero(gen)[0]:
+            mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
+        assert np.abs(a[0][:, mask] - b[0][:, mask]).max() <= 1e-12
+        assert np.abs(a[3][gen] - b[3][gen]).max() <= 1e-12
+        o.vertex_step(1.0, 1.0); o.edge_step(1.0)
