@@ -49,7 +49,7 @@ template <class LaneT> struct GpuExec {
         __syncthreads();
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         if (lane == 0) acc[phase] += t1 - t0;
-        phase = (phase == 21) ? 5 : phase + 1;   // 5 prologue phases, then 17 per Newton iteration
+        phase = (phase == 12) ? 4 : phase + 1;   // 4 prologue phases, then 9 per Newton iteration
     }
 #else
     template <class F> __device__ __forceinline__ void each(F &&f)
@@ -59,6 +59,35 @@ template <class LaneT> struct GpuExec {
     }
 #endif
     template <class P> __device__ __forceinline__ bool all(P &&p) { return __all(p(L) ? 1 : 0) != 0; }
+    template <class F> __device__ __forceinline__ int wave_max(F &&f)
+    {
+        int m = f(L);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+        return __builtin_amdgcn_readfirstlane(m);
+    }
+    // segmented reduction over the consecutive block lanes of one side of a vertex (vertex_program.inc):
+    // shuffle-down tree, nsteps is wave-uniform; all 64 lanes execute it, non-contributors pass the identity.
+    template <int CNT>
+    __device__ __forceinline__ void seg_reduce(LaneT &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
+                                               bool contributes, int nsteps)
+    {
+        for (int s = 0; s < nsteps; ++s) {
+            const bool ok = (L.segmask >> s) & 1;
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) {
+                const double t = __shfl_down(v[k], 1 << s, 64);
+                if (k == special && op == 1) v[k] = ok ? fmin(v[k], t) : v[k];
+                else if (k == special && op == 2) v[k] = ok ? fmax(v[k], t) : v[k];
+                else v[k] = ok ? v[k] + t : v[k];
+            }
+        }
+        if (contributes && L.seg_head) {
+            double *dst = L.out ? sout : sin;
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) dst[k] = v[k];
+        }
+    }
     __device__ __forceinline__ void count(int *c, int fails, int iters)
     {
         if (fails) atomicAdd(&c[0], fails);
@@ -101,8 +130,7 @@ __global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Ar
     const int dual_rows = PROG::lds_duals ? 2 * a.MM : 0;
     S.lamA = smem;
     S.lamB = S.lamA + dual_rows * WAVE;
-    S.stage = S.lamB + dual_rows * WAVE;
-    S.slots = S.stage + RED_CHUNK * WAVE;
+    S.slots = S.lamB + dual_rows * WAVE;
     using LaneT = typename PROG::template LaneT<N>;
     LaneT L;
 #ifdef GCS_PHASE_TIMING

@@ -20,6 +20,21 @@ template <int N> struct CpuExec {
     template <class F> void each(F &&f) { for (int l = 0; l < WAVE; ++l) f(Ls[l], l); }
     template <class P> bool all(P &&p) { for (int l = 0; l < WAVE; ++l) if (!p(Ls[l])) return false; return true; }
     void count(int *c, int fails, int iters) { c[0] += fails; c[1] += iters; }
+    template <class F> int wave_max(F &&f) { int m = 0; for (int l = 0; l < WAVE; ++l) m = std::max(m, f(Ls[l])); return m; }
+    // lanes run in increasing order inside a phase: the head lane of a segment initialises the sum, the
+    // following lanes of the segment accumulate (the GPU does the same reduction as a shuffle tree)
+    template <int CNT> void seg_reduce(Lane<N> &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
+                                       bool contributes, int)
+    {
+        if (!contributes) return;
+        double *dst = L.out ? sout : sin;
+        for (int k = 0; k < CNT; ++k) {
+            if (L.seg_head) dst[k] = v[k];
+            else if (k == special && op == 1) dst[k] = fmin(dst[k], v[k]);
+            else if (k == special && op == 2) dst[k] = fmax(dst[k], v[k]);
+            else dst[k] += v[k];
+        }
+    }
 };
 
 extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const int *inc_edge, const int *inc_out,
@@ -66,8 +81,8 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
         std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
         WaveShared S;
         const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
-        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE; S.stage = S.lamB + dual_rows * WAVE;
-        S.slots = S.stage + RED_CHUNK * WAVE;
+        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
+        S.slots = S.lamB + dual_rows * WAVE;
         run_vertex_program<2, double>(*ex, w, a, S, rho, mu_scale);
     }
     delete ex;
@@ -86,6 +101,21 @@ template <int N> struct CpuExec {
     template <class F> void each(F &&f) { for (int l = 0; l < WAVE; ++l) f(Ls[l], l); }
     template <class P> bool all(P &&p) { for (int l = 0; l < WAVE; ++l) if (!p(Ls[l])) return false; return true; }
     void count(int *c, int fails, int iters) { c[0] += fails; c[1] += iters; }
+    template <class F> int wave_max(F &&f) { int m = 0; for (int l = 0; l < WAVE; ++l) m = std::max(m, f(Ls[l])); return m; }
+    // lanes run in increasing order inside a phase: the head lane of a segment initialises the sum, the
+    // following lanes of the segment accumulate (the GPU does the same reduction as a shuffle tree)
+    template <int CNT> void seg_reduce(Lane<N> &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
+                                       bool contributes, int)
+    {
+        if (!contributes) return;
+        double *dst = L.out ? sout : sin;
+        for (int k = 0; k < CNT; ++k) {
+            if (L.seg_head) dst[k] = v[k];
+            else if (k == special && op == 1) dst[k] = fmin(dst[k], v[k]);
+            else if (k == special && op == 2) dst[k] = fmax(dst[k], v[k]);
+            else dst[k] += v[k];
+        }
+    }
 };
 
 extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const int *inc_edge, const int *inc_out,
@@ -132,8 +162,8 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
         std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
         WaveShared S;
         const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
-        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE; S.stage = S.lamB + dual_rows * WAVE;
-        S.slots = S.stage + RED_CHUNK * WAVE;
+        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
+        S.slots = S.lamB + dual_rows * WAVE;
         run_vertex_program<2, double>(*ex, w, a, S, rho, mu_scale);
     }
     delete ex;
