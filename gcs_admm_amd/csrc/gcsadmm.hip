@@ -556,6 +556,17 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     int slots_cap = MAX_SLOTS;
     while (slots_cap > 1 && lds_need(slots_cap) > 160 * 1024) --slots_cap;
     if (lds_need(slots_cap) > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
+    // small graphs: spread the vertices over more wavefronts (a wavefront runs as long as its slowest
+    // vertex, and the chip has 1024 one-wave-per-SIMD slots to fill before packing pays)
+    {
+        int n_generic = 0;
+        for (int v = 0; v < V; ++v) {
+            const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
+            n_generic += !(v == g->src || v == g->dst || din == 0 || d - din == 0);
+        }
+        const int want = std::max(1, (n_generic + 1023) / 1024);
+        slots_cap = std::min(slots_cap, want);
+    }
     int lanes = 0, slots = 0, max_slots_used = 0;
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
