@@ -8,8 +8,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "gcsadmm.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "vertex_program.h"), os.path.join(ROOT, "include", "gcsadmm.h")]
+CSRC = os.path.join(HERE, "csrc")
+SRCS = [os.path.join(CSRC, "gcsadmm.hip"), os.path.join(CSRC, "gcsadmm_dims.hip")]
+DEPS = SRCS + [os.path.join(CSRC, f) for f in ("vertex_program.h", "vertex_program.inc", "vertex_kernel.h")] + [
+    os.path.join(ROOT, "include", "gcsadmm.h")]
 OUT = os.path.join(HERE, "libgcsadmm.so")
 
 
@@ -21,13 +23,22 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Two translation units compiled concurrently (the n = 3 / 6 instantiations take minutes), then linked."""
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"), SRC, "-o", OUT]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    objs, procs = [], []
+    for src in SRCS:
+        obj = os.path.join(HERE, os.path.basename(src).replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in DEPS):
+            procs.append((src, subprocess.Popen([hipcc()] + flags + ["-c", src, "-o", obj])))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT])
     return OUT
 
 

@@ -19,221 +19,14 @@
 #include <vector>
 
 #include "gcsadmm.h"
-#include "vertex_program.h"
+#include "vertex_kernel.h"
 
 namespace {
 
 using namespace gcs;
+using namespace gcsadmm_k;
 
 constexpr int EDGE_BLOCK = 256;
-constexpr int MAX_SPECIAL_DEG = 256;
-
-// -------------------------------------------------------------------------------------------------
-// vertex kernel
-// -------------------------------------------------------------------------------------------------
-#ifdef GCS_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[64];
-#endif
-
-template <class LaneT> struct GpuExec {
-    LaneT &L;
-    int lane;
-#ifdef GCS_PHASE_TIMING
-    // diagnostic build only: cycles per barrier-separated phase, summed over wavefronts
-    int phase = 0;
-    unsigned long long *acc;
-    template <class F> __device__ __forceinline__ void each(F &&f)
-    {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        f(L, lane);
-        __syncthreads();
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        if (lane == 0) acc[phase] += t1 - t0;
-        phase = (phase == 12) ? 4 : phase + 1;   // 4 prologue phases, then 9 per Newton iteration
-    }
-#else
-    template <class F> __device__ __forceinline__ void each(F &&f)
-    {
-        f(L, lane);
-        __syncthreads();
-    }
-#endif
-    template <class P> __device__ __forceinline__ bool all(P &&p) { return __all(p(L) ? 1 : 0) != 0; }
-    template <class F> __device__ __forceinline__ int wave_max(F &&f)
-    {
-        int m = f(L);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-        return __builtin_amdgcn_readfirstlane(m);
-    }
-    // segmented reduction over the consecutive block lanes of one side of a vertex (vertex_program.inc):
-    // shuffle-down tree, nsteps is wave-uniform; all 64 lanes execute it, non-contributors pass the identity.
-    template <int CNT>
-    __device__ __forceinline__ void seg_reduce(LaneT &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
-                                               bool contributes, int nsteps)
-    {
-        for (int s = 0; s < nsteps; ++s) {
-            const bool ok = (L.segmask >> s) & 1;
-#pragma unroll
-            for (int k = 0; k < CNT; ++k) {
-                const double t = __shfl_down(v[k], 1 << s, 64);
-                if (k == special && op == 1) v[k] = ok ? fmin(v[k], t) : v[k];
-                else if (k == special && op == 2) v[k] = ok ? fmax(v[k], t) : v[k];
-                else v[k] = ok ? v[k] + t : v[k];
-            }
-        }
-        if (contributes && L.seg_head) {
-            double *dst = L.out ? sout : sin;
-#pragma unroll
-            for (int k = 0; k < CNT; ++k) dst[k] = v[k];
-        }
-    }
-    __device__ __forceinline__ void count(int *c, int fails, int iters)
-    {
-        if (fails) atomicAdd(&c[0], fails);
-        atomicAdd(&c[1], iters);
-    }
-};
-
-// the two instantiations of the wavefront program (vertex_program.h)
-struct ProgGeneric {   // any facet count per polytope, facet-row duals in LDS
-    template <int N> using LaneT = gcs::Lane<N>;
-    template <class T> using Args = gcs::VertexArgs<T>;
-    using Shared = gcs::WaveShared;
-    static constexpr bool lds_duals = true;
-    template <int N, class T, class EX>
-    static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
-    {
-        gcs::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
-    }
-};
-struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet loops, row duals in registers
-    template <int N> using LaneT = gcs_m4::Lane<N>;
-    template <class T> using Args = gcs_m4::VertexArgs<T>;
-    using Shared = gcs_m4::WaveShared;
-    static constexpr bool lds_duals = false;
-    template <int N, class T, class EX>
-    static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
-    {
-        gcs_m4::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
-    }
-};
-
-template <class PROG, int N, class T>
-__global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Args<T> a, const gcsadmm_control_block *cb)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (cb->status != GCSADMM_RUNNING) return;
-    const double rho = cb->rho, mu_scale = cb->mu_scale;
-    typename PROG::Shared S;
-    S.MM = a.MM;
-    const int dual_rows = PROG::lds_duals ? 2 * a.MM : 0;
-    S.lamA = smem;
-    S.lamB = S.lamA + dual_rows * WAVE;
-    S.slots = S.lamB + dual_rows * WAVE;
-    using LaneT = typename PROG::template LaneT<N>;
-    LaneT L;
-#ifdef GCS_PHASE_TIMING
-    __shared__ unsigned long long acc[64];
-    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
-    __syncthreads();
-    GpuExec<LaneT> ex{L, (int)threadIdx.x, 0, acc};
-#else
-    GpuExec<LaneT> ex{L, (int)threadIdx.x};
-#endif
-    PROG::template run<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
-#ifdef GCS_PHASE_TIMING
-    __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(&g_phase_cycles[threadIdx.x], acc[threadIdx.x]);
-#endif
-}
-
-// -------------------------------------------------------------------------------------------------
-// special vertices: s / t are points (utils.py:12-28, boxes of half-width 1e-6) -> the sub-problem
-// collapses to a separable quadratic over the simplex of the live side; a vertex with no incoming or
-// no outgoing edge carries no flow.  One thread per vertex.
-// -------------------------------------------------------------------------------------------------
-template <class T> struct SpecialArgs {
-    int count;
-    const int *vtx;     // vertex ids
-    const int *kind;    // 1 = source, 2 = target, 0 = no-flow
-    const int *inc_ptr, *deg_in, *inc_edge;
-    const double *center;
-    int E, NI;
-    const T *zedge, *mu;
-    T *copy;
-    double *xv, *zv, *yv;
-    double eps_edge;
-};
-
-template <int N, class T>
-__global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb)
-{
-    if (cb->status != GCSADMM_RUNNING) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.count) return;
-    const double rho = cb->rho, mu_scale = cb->mu_scale;
-    const int v = a.vtx[i], kind = a.kind[i];
-    const int lo = a.inc_ptr[v], d = a.inc_ptr[v + 1] - lo, d_in = a.deg_in[v];
-    double cen[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) cen[k] = a.center[(size_t)v * N + k];
-    auto target = [&](int w, int k) -> double {
-        const int inc = lo + k, e = a.inc_edge[inc];
-        return (double)a.zedge[(size_t)w * a.E + e] - mu_scale * (double)a.mu[(size_t)w * a.NI + inc];
-    };
-    const bool is_src = kind == 1, is_dst = kind == 2;
-    const int live_lo = is_src ? d_in : 0, live_hi = is_src ? d : (is_dst ? d_in : 0);
-    const int na = live_hi - live_lo;
-    double vals[MAX_SPECIAL_DEG];
-    double tau = 0.0;
-    if (na > 0) {
-        double pp = 0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) pp += cen[k] * cen[k];
-        const double aq = is_src ? 2 * pp + 1 : pp + 1;
-        for (int e = live_lo; e < live_hi; ++e) {
-            double cc = target(2 * N, e);
-#pragma unroll
-            for (int k = 0; k < N; ++k) cc += cen[k] * (is_src ? target(k, e) + target(N + k, e) : target(N + k, e));
-            vals[e - live_lo] = (cc - a.eps_edge / rho) / aq;
-        }
-        // threshold of the Euclidean projection onto the simplex: sort descending (insertion), scan
-        double u[MAX_SPECIAL_DEG];
-        for (int q = 0; q < na; ++q) u[q] = vals[q];
-        for (int q = 1; q < na; ++q) {
-            const double x = u[q];
-            int j = q - 1;
-            while (j >= 0 && u[j] < x) { u[j + 1] = u[j]; --j; }
-            u[j + 1] = x;
-        }
-        double css = 0;
-        for (int k = 0; k < na; ++k) {
-            css += u[k];
-            if (u[k] * (k + 1) > css - 1.0) tau = (css - 1.0) / (k + 1);
-        }
-    }
-    for (int e = 0; e < d; ++e) {
-        const bool live = e >= live_lo && e < live_hi;
-        double ye = 0.0;
-        if (live) { ye = vals[e - live_lo] - tau; ye = ye > 0 ? ye : 0.0; }
-        const bool outgoing = e >= d_in;
-        const int inc = lo + e;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double yc = (kind != 0) ? ye * cen[k] : 0.0;
-            a.copy[(size_t)k * a.NI + inc] = (T)(outgoing ? yc : target(k, e));
-            a.copy[(size_t)(N + k) * a.NI + inc] = (T)yc;
-        }
-        a.copy[(size_t)(2 * N) * a.NI + inc] = (T)ye;
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        a.xv[(size_t)v * 2 * N + k] = a.xv[(size_t)v * 2 * N + N + k] = cen[k];
-        a.zv[(size_t)v * 2 * N + k] = a.zv[(size_t)v * 2 * N + N + k] = (kind != 0) ? cen[k] : 0.0;
-    }
-    a.yv[v] = (kind != 0) ? 1.0 : 0.0;
-}
 
 // -------------------------------------------------------------------------------------------------
 // edge kernel: one thread per directed edge, all c coupled words
@@ -427,33 +220,16 @@ template <class U> static hipError_t upload(U **dst, const U *src, size_t count)
     return hipMemset(*dst, 0, count * sizeof(U));
 }
 
-template <class PROG, class T> static void launch_vertex_prog(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
-{
-    typename PROG::template Args<T> a;
-    a.n_waves = h->n_waves; a.wave_slot_ptr = h->d_wave_slot_ptr; a.wave_vtx = h->d_wave_vtx;
-    a.inc_ptr = h->d_inc_ptr; a.deg_in = h->d_deg_in; a.inc_edge = h->d_inc_edge; a.poly_ptr = h->d_poly_ptr;
-    a.poly_A = h->d_poly_A; a.poly_bc = h->d_poly_bc; a.center = h->d_center;
-    a.E = h->E; a.NI = h->NI; a.MM = h->MM;
-    a.zedge = (const T *)st->zedge; a.mu = (const T *)st->mu; a.copy = (T *)st->copy;
-    a.xv = st->xv; a.zv = st->zv; a.yv = st->yv; a.counters = h->d_counters;
-    a.eps_edge = h->params.eps_edge; a.ipm_tol = h->params.ipm_tol; a.ipm_max_iter = h->params.ipm_max_iter;
-    hipLaunchKernelGGL((vertex_kernel<PROG, 2, T>), dim3(h->n_waves), dim3(WAVE), h->lds_bytes, s, a, h->d_cb);
-}
+static VertexLaunchDesc make_launch_desc(gcsadmm_handle h, const gcsadmm_state *st);
 
+// n = 2 is the tuned instantiation (plus the m = 4 program) and lives in this translation unit; n = 3 and n = 6
+// run the same wavefront program, functional but spilling heavily (the reduced border system has 4n+1
+// unknowns: 25 at n = 6), and are compiled separately (gcsadmm_dims.hip) because they take minutes to build
 template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
 {
-    if (h->n_waves > 0) {
-        if (h->all_m4) launch_vertex_prog<ProgM4, T>(h, st, s);
-        else launch_vertex_prog<ProgGeneric, T>(h, st, s);
-    }
-    if (h->n_special > 0) {
-        SpecialArgs<T> a;
-        a.count = h->n_special; a.vtx = h->d_special_vtx; a.kind = h->d_special_kind;
-        a.inc_ptr = h->d_inc_ptr; a.deg_in = h->d_deg_in; a.inc_edge = h->d_inc_edge; a.center = h->d_center;
-        a.E = h->E; a.NI = h->NI; a.zedge = (const T *)st->zedge; a.mu = (const T *)st->mu; a.copy = (T *)st->copy;
-        a.xv = st->xv; a.zv = st->zv; a.yv = st->yv; a.eps_edge = h->params.eps_edge;
-        hipLaunchKernelGGL((special_kernel<2, T>), dim3((h->n_special + 63) / 64), dim3(64), 0, s, a, h->d_cb);
-    }
+    const VertexLaunchDesc d = make_launch_desc(h, st);
+    if (h->n == 2) launch_vertex_dim<2, T>(d, s);
+    else gcsadmm_launch_vertex_hi(h->n, h->dtype, d, s);
     HIPCHK(h, hipGetLastError());
     return GCSADMM_OK;
 }
@@ -475,6 +251,20 @@ static bool state_ok(gcsadmm_handle h, const gcsadmm_state *st)
     if (!h || !st || !st->copy || !st->mu || !st->zedge || !st->xv || !st->zv || !st->yv) { if (h) h->err = "null state pointer"; return false; }
     if (!h->params_set) { h->err = "gcsadmm_reset has not been called"; return false; }
     return true;
+}
+
+static VertexLaunchDesc make_launch_desc(gcsadmm_handle h, const gcsadmm_state *st)
+{
+    VertexLaunchDesc d;
+    d.n_waves = h->n_waves; d.n_special = h->n_special; d.all_m4 = h->all_m4; d.lds_bytes = h->lds_bytes;
+    d.wave_slot_ptr = h->d_wave_slot_ptr; d.wave_vtx = h->d_wave_vtx; d.special_vtx = h->d_special_vtx; d.special_kind = h->d_special_kind;
+    d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
+    d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
+    d.E = h->E; d.NI = h->NI; d.MM = h->MM;
+    d.zedge = st->zedge; d.mu = st->mu; d.copy = st->copy; d.xv = st->xv; d.zv = st->zv; d.yv = st->yv;
+    d.counters = h->d_counters; d.cb = h->d_cb;
+    d.eps_edge = h->params.eps_edge; d.ipm_tol = h->params.ipm_tol; d.ipm_max_iter = h->params.ipm_max_iter;
+    return d;
 }
 
 extern "C" {
@@ -499,7 +289,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     if (out) *out = nullptr;
     auto fail = [&](gcsadmm_status st, const std::string &msg) { g_create_error = msg; return st; };
     if (!g || !out) return fail(GCSADMM_ERR_BAD_ARG, "null descriptor or output pointer");
-    if (g->n != 2) return fail(GCSADMM_ERR_UNSUPPORTED, "only n = 2 is implemented by the current vertex kernel");
+    if (g->n != 2 && g->n != 3 && g->n != 6) return fail(GCSADMM_ERR_UNSUPPORTED, "the vertex kernel is instantiated for n = 2, 3 and 6");
     if (g->num_vertices < 0 || g->num_edges < 0) return fail(GCSADMM_ERR_BAD_ARG, "negative size");
     if (!g->inc_ptr || !g->poly_ptr || (g->num_edges > 0 && (!g->inc_edge || !g->inc_out || !g->edge_inc_tail || !g->edge_inc_head)) ||
         (g->num_vertices > 0 && (!g->poly_A || !g->poly_b || !g->center)))
@@ -546,7 +336,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
 
     // classify vertices and pack the generic ones into wavefronts: d+1 lanes each
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx;
-    bool all_m4 = true;
+    bool all_m4 = (n == 2);
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
         const bool generic = !(v == g->src || v == g->dst || din == 0 || d - din == 0);
@@ -628,9 +418,8 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_sums, (const double *)nullptr, 5);
 #undef UP
     if (h->lds_bytes > 48 * 1024) {
-        const void *fn = h->all_m4 ? (h->dtype == GCSADMM_F64 ? (const void *)vertex_kernel<ProgM4, 2, double> : (const void *)vertex_kernel<ProgM4, 2, float>)
-                                   : (h->dtype == GCSADMM_F64 ? (const void *)vertex_kernel<ProgGeneric, 2, double> : (const void *)vertex_kernel<ProgGeneric, 2, float>);
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+        if (h->n == 2) e = h->dtype == GCSADMM_F64 ? set_lds_attr<2, double>(h->all_m4, h->lds_bytes) : set_lds_attr<2, float>(h->all_m4, h->lds_bytes);
+        else e = gcsadmm_lds_attr_hi(h->n, h->dtype, h->lds_bytes);
         if (e != hipSuccess) return bail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     *out = h;

@@ -1,0 +1,275 @@
+// vertex_kernel.h -- device-side wrapper of the wavefront program (vertex_program.h): the kernel template,
+// the closed-form kernel for s / t / no-flow vertices, and the host-side launch helpers shared by the two
+// translation units that instantiate them (gcsadmm.hip: n = 2; gcsadmm_dims.hip: n = 3, 6).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gcsadmm.h"
+#include "vertex_program.h"
+
+namespace gcsadmm_k {
+
+using gcs::WAVE;
+constexpr int MAX_SPECIAL_DEG = 256;
+
+// everything a vertex-step launch needs, as plain pointers (device) and scalars
+struct VertexLaunchDesc {
+    int n_waves, n_special, all_m4, lds_bytes;
+    const int *wave_slot_ptr, *wave_vtx, *special_vtx, *special_kind;
+    const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
+    const double *poly_A, *poly_bc, *center;
+    int E, NI, MM;
+    void *zedge, *mu, *copy;
+    double *xv, *zv, *yv;
+    int *counters;
+    const gcsadmm_control_block *cb;
+    double eps_edge, ipm_tol;
+    int ipm_max_iter;
+};
+
+#ifdef GCS_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[64];
+#endif
+
+template <class LaneT> struct GpuExec {
+    LaneT &L;
+    int lane;
+#ifdef GCS_PHASE_TIMING
+    // diagnostic build only: cycles per barrier-separated phase, summed over wavefronts
+    int phase = 0;
+    unsigned long long *acc;
+    template <class F> __device__ __forceinline__ void each(F &&f)
+    {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        f(L, lane);
+        __syncthreads();
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) acc[phase] += t1 - t0;
+        phase = (phase == 12) ? 4 : phase + 1;   // 4 prologue phases, then 9 per Newton iteration
+    }
+#else
+    template <class F> __device__ __forceinline__ void each(F &&f)
+    {
+        f(L, lane);
+        __syncthreads();
+    }
+#endif
+    template <class P> __device__ __forceinline__ bool all(P &&p) { return __all(p(L) ? 1 : 0) != 0; }
+    template <class F> __device__ __forceinline__ int wave_max(F &&f)
+    {
+        int m = f(L);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+        return __builtin_amdgcn_readfirstlane(m);
+    }
+    // segmented reduction over the consecutive block lanes of one side of a vertex (vertex_program.inc):
+    // shuffle-down tree, nsteps is wave-uniform; all 64 lanes execute it, non-contributors pass the identity.
+    template <int CNT>
+    __device__ __forceinline__ void seg_reduce(LaneT &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
+                                               bool contributes, int nsteps)
+    {
+        for (int s = 0; s < nsteps; ++s) {
+            const bool ok = (L.segmask >> s) & 1;
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) {
+                const double t = __shfl_down(v[k], 1 << s, 64);
+                if (k == special && op == 1) v[k] = ok ? fmin(v[k], t) : v[k];
+                else if (k == special && op == 2) v[k] = ok ? fmax(v[k], t) : v[k];
+                else v[k] = ok ? v[k] + t : v[k];
+            }
+        }
+        if (contributes && L.seg_head) {
+            double *dst = L.out ? sout : sin;
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) dst[k] = v[k];
+        }
+    }
+    __device__ __forceinline__ void count(int *c, int fails, int iters)
+    {
+        if (fails) atomicAdd(&c[0], fails);
+        atomicAdd(&c[1], iters);
+    }
+};
+
+// the two instantiations of the wavefront program (vertex_program.h)
+struct ProgGeneric {   // any facet count per polytope, facet-row duals in LDS
+    template <int N> using LaneT = gcs::Lane<N>;
+    template <class T> using Args = gcs::VertexArgs<T>;
+    using Shared = gcs::WaveShared;
+    static constexpr bool lds_duals = true;
+    template <int N, class T, class EX>
+    static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
+    {
+        gcs::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
+    }
+};
+struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet loops, row duals in registers
+    template <int N> using LaneT = gcs_m4::Lane<N>;
+    template <class T> using Args = gcs_m4::VertexArgs<T>;
+    using Shared = gcs_m4::WaveShared;
+    static constexpr bool lds_duals = false;
+    template <int N, class T, class EX>
+    static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
+    {
+        gcs_m4::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
+    }
+};
+
+template <class PROG, int N, class T>
+__global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Args<T> a, const gcsadmm_control_block *cb)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (cb->status != GCSADMM_RUNNING) return;
+    const double rho = cb->rho, mu_scale = cb->mu_scale;
+    typename PROG::Shared S;
+    S.MM = a.MM;
+    const int dual_rows = PROG::lds_duals ? 2 * a.MM : 0;
+    S.lamA = smem;
+    S.lamB = S.lamA + dual_rows * WAVE;
+    S.slots = S.lamB + dual_rows * WAVE;
+    using LaneT = typename PROG::template LaneT<N>;
+    LaneT L;
+#ifdef GCS_PHASE_TIMING
+    __shared__ unsigned long long acc[64];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+    __syncthreads();
+    GpuExec<LaneT> ex{L, (int)threadIdx.x, 0, acc};
+#else
+    GpuExec<LaneT> ex{L, (int)threadIdx.x};
+#endif
+    PROG::template run<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
+#ifdef GCS_PHASE_TIMING
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&g_phase_cycles[threadIdx.x], acc[threadIdx.x]);
+#endif
+}
+
+// -------------------------------------------------------------------------------------------------
+// special vertices: s / t are points (utils.py:12-28, boxes of half-width 1e-6) -> the sub-problem
+// collapses to a separable quadratic over the simplex of the live side; a vertex with no incoming or
+// no outgoing edge carries no flow.  One thread per vertex.
+// -------------------------------------------------------------------------------------------------
+template <class T> struct SpecialArgs {
+    int count;
+    const int *vtx;     // vertex ids
+    const int *kind;    // 1 = source, 2 = target, 0 = no-flow
+    const int *inc_ptr, *deg_in, *inc_edge;
+    const double *center;
+    int E, NI;
+    const T *zedge, *mu;
+    T *copy;
+    double *xv, *zv, *yv;
+    double eps_edge;
+};
+
+template <int N, class T>
+__global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.count) return;
+    const double rho = cb->rho, mu_scale = cb->mu_scale;
+    const int v = a.vtx[i], kind = a.kind[i];
+    const int lo = a.inc_ptr[v], d = a.inc_ptr[v + 1] - lo, d_in = a.deg_in[v];
+    double cen[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) cen[k] = a.center[(size_t)v * N + k];
+    auto target = [&](int w, int k) -> double {
+        const int inc = lo + k, e = a.inc_edge[inc];
+        return (double)a.zedge[(size_t)w * a.E + e] - mu_scale * (double)a.mu[(size_t)w * a.NI + inc];
+    };
+    const bool is_src = kind == 1, is_dst = kind == 2;
+    const int live_lo = is_src ? d_in : 0, live_hi = is_src ? d : (is_dst ? d_in : 0);
+    const int na = live_hi - live_lo;
+    double vals[MAX_SPECIAL_DEG];
+    double tau = 0.0;
+    if (na > 0) {
+        double pp = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) pp += cen[k] * cen[k];
+        const double aq = is_src ? 2 * pp + 1 : pp + 1;
+        for (int e = live_lo; e < live_hi; ++e) {
+            double cc = target(2 * N, e);
+#pragma unroll
+            for (int k = 0; k < N; ++k) cc += cen[k] * (is_src ? target(k, e) + target(N + k, e) : target(N + k, e));
+            vals[e - live_lo] = (cc - a.eps_edge / rho) / aq;
+        }
+        // threshold of the Euclidean projection onto the simplex: sort descending (insertion), scan
+        double u[MAX_SPECIAL_DEG];
+        for (int q = 0; q < na; ++q) u[q] = vals[q];
+        for (int q = 1; q < na; ++q) {
+            const double x = u[q];
+            int j = q - 1;
+            while (j >= 0 && u[j] < x) { u[j + 1] = u[j]; --j; }
+            u[j + 1] = x;
+        }
+        double css = 0;
+        for (int k = 0; k < na; ++k) {
+            css += u[k];
+            if (u[k] * (k + 1) > css - 1.0) tau = (css - 1.0) / (k + 1);
+        }
+    }
+    for (int e = 0; e < d; ++e) {
+        const bool live = e >= live_lo && e < live_hi;
+        double ye = 0.0;
+        if (live) { ye = vals[e - live_lo] - tau; ye = ye > 0 ? ye : 0.0; }
+        const bool outgoing = e >= d_in;
+        const int inc = lo + e;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double yc = (kind != 0) ? ye * cen[k] : 0.0;
+            a.copy[(size_t)k * a.NI + inc] = (T)(outgoing ? yc : target(k, e));
+            a.copy[(size_t)(N + k) * a.NI + inc] = (T)yc;
+        }
+        a.copy[(size_t)(2 * N) * a.NI + inc] = (T)ye;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a.xv[(size_t)v * 2 * N + k] = a.xv[(size_t)v * 2 * N + N + k] = cen[k];
+        a.zv[(size_t)v * 2 * N + k] = a.zv[(size_t)v * 2 * N + N + k] = (kind != 0) ? cen[k] : 0.0;
+    }
+    a.yv[v] = (kind != 0) ? 1.0 : 0.0;
+}
+
+
+template <class PROG, int N, class T> static void launch_vertex_prog(const VertexLaunchDesc &d, hipStream_t s)
+{
+    typename PROG::template Args<T> a;
+    a.n_waves = d.n_waves; a.wave_slot_ptr = d.wave_slot_ptr; a.wave_vtx = d.wave_vtx;
+    a.inc_ptr = d.inc_ptr; a.deg_in = d.deg_in; a.inc_edge = d.inc_edge; a.poly_ptr = d.poly_ptr;
+    a.poly_A = d.poly_A; a.poly_bc = d.poly_bc; a.center = d.center;
+    a.E = d.E; a.NI = d.NI; a.MM = d.MM;
+    a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
+    a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
+    a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter;
+    hipLaunchKernelGGL((vertex_kernel<PROG, N, T>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb);
+}
+
+// vertex step for space dimension N: generic vertices (wavefront program) + special vertices (closed form)
+template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &d, hipStream_t s)
+{
+    if (d.n_waves > 0) {
+        if (N == 2 && d.all_m4) launch_vertex_prog<ProgM4, N, T>(d, s);
+        else launch_vertex_prog<ProgGeneric, N, T>(d, s);
+    }
+    if (d.n_special > 0) {
+        SpecialArgs<T> a;
+        a.count = d.n_special; a.vtx = d.special_vtx; a.kind = d.special_kind;
+        a.inc_ptr = d.inc_ptr; a.deg_in = d.deg_in; a.inc_edge = d.inc_edge; a.center = d.center;
+        a.E = d.E; a.NI = d.NI; a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
+        a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.eps_edge = d.eps_edge;
+        hipLaunchKernelGGL((special_kernel<N, T>), dim3((d.n_special + 63) / 64), dim3(64), 0, s, a, d.cb);
+    }
+}
+
+template <int N, class T> static hipError_t set_lds_attr(bool all_m4, int lds_bytes)
+{
+    const void *fn = (N == 2 && all_m4) ? (const void *)vertex_kernel<ProgM4, N, T> : (const void *)vertex_kernel<ProgGeneric, N, T>;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
+
+} // namespace gcsadmm_k
+
+// implemented in gcsadmm_dims.hip (n = 3, 6)
+void gcsadmm_launch_vertex_hi(int n, int dtype, const gcsadmm_k::VertexLaunchDesc &d, hipStream_t s);
+hipError_t gcsadmm_lds_attr_hi(int n, int dtype, int lds_bytes);

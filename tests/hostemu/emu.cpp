@@ -4,6 +4,7 @@
 // never shipped, never timed, and the product has no path into it.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "vertex_program.h"
@@ -43,7 +44,7 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
                                double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv, double *zv,
                                double *yv, int *counters, int *is_generic)
 {
-    if (n != 2) return 1;
+    if (n != 2 && n != 3 && n != 6) return 1;
     std::vector<int> deg_in(V, 0);
     int MM = 1;
     for (int v = 0; v < V; ++v) {
@@ -76,16 +77,21 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
     a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
     a.eps_edge = eps_edge; a.ipm_tol = ipm_tol; a.ipm_max_iter = ipm_max_iter;
     std::vector<double> smem(lds_doubles(n, MM, MAX_SLOTS));
-    auto *ex = new CpuExec<2>();
-    for (int w = 0; w < n_waves; ++w) {
-        std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
-        WaveShared S;
-        const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
-        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
-        S.slots = S.lamB + dual_rows * WAVE;
-        run_vertex_program<2, double>(*ex, w, a, S, rho, mu_scale);
-    }
-    delete ex;
+    auto run_all = [&](auto *ex, auto ntag) {
+        constexpr int NN = decltype(ntag)::value;
+        for (int w = 0; w < n_waves; ++w) {
+            std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
+            WaveShared S;
+            const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
+            S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
+            S.slots = S.lamB + dual_rows * WAVE;
+            run_vertex_program<NN, double>(*ex, w, a, S, rho, mu_scale);
+        }
+        delete ex;
+    };
+    if (n == 2) run_all(new CpuExec<2>(), std::integral_constant<int, 2>());
+    else if (n == 3) run_all(new CpuExec<3>(), std::integral_constant<int, 3>());
+    else run_all(new CpuExec<6>(), std::integral_constant<int, 6>());
     return 0;
 }
 
@@ -124,7 +130,7 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
                                double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv, double *zv,
                                double *yv, int *counters, int *is_generic)
 {
-    if (n != 2) return 1;
+    if (n != 2 && n != 3 && n != 6) return 1;
     std::vector<int> deg_in(V, 0);
     int MM = 1;
     for (int v = 0; v < V; ++v) {
@@ -157,16 +163,21 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
     a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
     a.eps_edge = eps_edge; a.ipm_tol = ipm_tol; a.ipm_max_iter = ipm_max_iter;
     std::vector<double> smem(lds_doubles(n, MM, MAX_SLOTS));
-    auto *ex = new CpuExec<2>();
-    for (int w = 0; w < n_waves; ++w) {
-        std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
-        WaveShared S;
-        const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
-        S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
-        S.slots = S.lamB + dual_rows * WAVE;
-        run_vertex_program<2, double>(*ex, w, a, S, rho, mu_scale);
-    }
-    delete ex;
+    auto run_all = [&](auto *ex, auto ntag) {
+        constexpr int NN = decltype(ntag)::value;
+        for (int w = 0; w < n_waves; ++w) {
+            std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
+            WaveShared S;
+            const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
+            S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
+            S.slots = S.lamB + dual_rows * WAVE;
+            run_vertex_program<NN, double>(*ex, w, a, S, rho, mu_scale);
+        }
+        delete ex;
+    };
+    if (n == 2) run_all(new CpuExec<2>(), std::integral_constant<int, 2>());
+    else if (n == 3) run_all(new CpuExec<3>(), std::integral_constant<int, 3>());
+    else run_all(new CpuExec<6>(), std::integral_constant<int, 6>());
     return 0;
 }
 

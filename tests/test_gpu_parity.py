@@ -203,3 +203,29 @@ def test_partitioned_handles_match_single(torch_gpu):
     full = single.zedge.cpu().numpy()
     for p, d in zip(parts, devs):
         assert np.allclose(d.zedge.cpu().numpy(), full[:, p.edge_global], rtol=0, atol=5e-4)
+
+
+@pytest.mark.parametrize("n", [3, 6])
+def test_other_space_dimensions(torch_gpu, oracle_lib, n):
+    """BASELINE config 5 is a GCS in R^6: the same wavefront program instantiated for n = 3 and n = 6
+    (functional, not yet tuned) against the oracle, step by step and over a short run."""
+    torch = torch_gpu
+    g = lattice_boxes(6, 5, n=n, seed=1)
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    d = _solver(g)
+    d.reset(max_it=50)
+    worst = 0.0
+    for it in range(10):
+        d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu.copy_(torch.from_numpy(o.mu))
+        d.vertex_step()
+        assert o.vertex_step(1.0, 1.0) == 0
+        copy = d.copy.cpu().numpy()
+        assert np.isfinite(copy).all()
+        worst = max(worst, np.abs(copy - o.copy).max())
+        o.edge_step(1.0)
+    assert worst <= 2e-3
+    d2 = _solver(g)
+    res = d2.solve(max_it=40, eps_abs=0.0, eps_rel=0.0)
+    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=40, eps_abs=0.0, eps_rel=0.0)
+    assert res["iterations"] == ora["iterations"] == 41 and res["inner_failures"] == 0
+    assert np.all(np.abs(res["pri_res_seq"] - ora["pri_res_seq"]) <= 2e-4 + 1e-3 * np.abs(ora["pri_res_seq"]))

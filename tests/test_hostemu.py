@@ -83,3 +83,18 @@ def test_fixed_facet_variant_equals_generic(emu, oracle_lib):
         assert np.abs(a[0][:, mask] - b[0][:, mask]).max() <= 1e-12
         assert np.abs(a[3][gen] - b[3][gen]).max() <= 1e-12
         o.vertex_step(1.0, 1.0); o.edge_step(1.0)
+
+
+@pytest.mark.parametrize("n", [3, 6])
+def test_emulated_wave_program_other_dimensions(emu, oracle_lib, n):
+    from gcs_admm_amd.graph import lattice_boxes
+    g = lattice_boxes(5, 4, n=n, seed=1)
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    for it in range(6):
+        copy, xv, zv, yv, cnt, gen = emu_step(emu, g, o.zedge.copy(), o.mu.copy(), 1.0, 1.0)
+        assert cnt[0] == 0 and o.vertex_step(1.0, 1.0) == 0
+        mask = np.zeros(2 * g.num_edges, bool)
+        for v in np.nonzero(gen)[0]:
+            mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
+        assert np.abs(copy[:, mask] - o.copy[:, mask]).max() <= 2e-3
+        o.edge_step(1.0)
