@@ -29,8 +29,12 @@ def make_workload(name, rank=0, world=1):
     if name == "benchmark4":
         case, g = load_fixture("benchmark4")
         return g, "f64", dict(case=case)
-    if name == "s10k":
+    if name == "s10k":       # BASELINE config 3
         return lattice_boxes(100, 100, seed=0), "f32", {}
+    if name == "s100k":      # BASELINE config 4's graph on one GPU
+        return lattice_boxes(316, 317, seed=0), "f32", {}
+    if name == "s6d":        # BASELINE config 5
+        return lattice_boxes(223, 224, n=6, seed=0), "f32", {}
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -50,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="benchmark4")
+    ap.add_argument("--workload", default="benchmark4", choices=["benchmark4", "s10k", "s100k", "s6d"])
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     import numpy as np
@@ -105,6 +109,18 @@ def main():
             pc = json.load(open(prof))
             traffic = 1024.0 * (2.0 * pc["FETCH_SIZE"]["vertex_kernel"]["mean_KB_per_launch"]
                                 + pc["WRITE_SIZE"]["vertex_kernel"]["mean_KB_per_launch"])
+        # model flops of one Newton iteration of one vertex (f64 flops, FMA = 2; analytic count of the kernel's
+        # arithmetic, not a hardware counter): facet-row passes 4 x ~52(n/2+1) per row pair, block algebra
+        # ~(2n+1)^3 * 10, border algebra ~(4n+1)^3 * 5.5
+        n_, cb_ = g.n, dev.read_control()
+        deg = np.diff(g.inc_ptr); mfac = np.diff(g.poly_ptr)
+        gen = np.ones(g.num_vertices, bool); gen[[g.src, g.dst]] = False
+        per_vertex = (deg + 1) * 2 * mfac * 210.0 * (n_ / 2.0) + deg * 10.0 * (2 * n_ + 1) ** 3 + 5.5 * (4 * n_ + 1) ** 3
+        it_per_vertex = cb_.inner_iters / max(int(gen.sum()), 1)
+        flops = float(per_vertex[gen].sum()) * it_per_vertex
+        out["roofline_fp"] = {"bound": "f64 vector", "achieved": flops / (v_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                              "frac": flops / (v_ms * 1e-3) / 1e12 / 78.6, "note": "model flops (analytic count), per vertex-step launch",
+                              "newton_iterations_per_vertex": it_per_vertex}
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": "vertex_kernel<2>", "avg_launch_ms": v_ms,
                            "algorithmic_bytes_per_launch": alg_bytes, "edge_step_avg_ms": e_ms,
@@ -134,7 +150,7 @@ def main():
             n_probe = 20 if args.workload == "benchmark4" else 2
             best, cores = 0.0, 1
             for th in sorted({1, 8, 16, 32, 64, 128, ncpu}):
-                if th > ncpu:
+                if th > ncpu or (th == 1 and g.num_vertices > 5000 and ncpu > 1):
                     continue
                 o = Oracle(g, ipm_tol=1e-9)
                 t0 = time.perf_counter()

@@ -25,7 +25,7 @@ import numpy as np
 
 __all__ = [
     "convert_pt_to_polytope", "build_graph", "delta", "polytopes_overlap",
-    "chebyshev_center", "GcsGraph", "graph_from_sets", "lattice_boxes",
+    "chebyshev_center", "bounding_box", "GcsGraph", "graph_from_sets", "lattice_boxes",
 ]
 
 
@@ -91,13 +91,24 @@ def build_graph(As: Dict[Hashable, np.ndarray], bs: Dict[Hashable, np.ndarray]):
     ``I_v_out[v]`` / ``I_v_in[v]`` in ``E`` order."""
     vertices = list(As.keys())
     nv = len(vertices)
-    ov = np.zeros((nv, nv), dtype=bool)
-    for i in range(nv):
-        for j in range(i + 1, nv):
-            ov[i, j] = ov[j, i] = polytopes_overlap(As[vertices[i]], bs[vertices[i]],
-                                                    As[vertices[j]], bs[vertices[j]])
-    edges = [(vertices[i], vertices[j]) for i in range(nv) for j in range(nv)
-             if i != j and ov[i, j]]
+    # the reference tests all |V|^2 ordered pairs with an LP each (utils.py:68-72); here only pairs whose
+    # axis-aligned bounding boxes touch are tested (sweep over the first coordinate), each unordered pair once
+    lo = np.empty((nv, np.asarray(As[vertices[0]]).shape[1])); hi = np.empty_like(lo)
+    for i, v in enumerate(vertices):
+        lo[i], hi[i] = bounding_box(As[v], bs[v])
+    pad = 1e-7
+    order = np.argsort(lo[:, 0], kind="stable")
+    pairs = set()
+    active: list = []
+    for i in order:
+        active = [j for j in active if hi[j, 0] + pad >= lo[i, 0]]
+        for j in active:
+            if np.all(lo[i] <= hi[j] + pad) and np.all(lo[j] <= hi[i] + pad):
+                a, b = (i, j) if i < j else (j, i)
+                if polytopes_overlap(As[vertices[a]], bs[vertices[a]], As[vertices[b]], bs[vertices[b]]):
+                    pairs.add((a, b)); pairs.add((b, a))
+        active.append(i)
+    edges = [(vertices[i], vertices[j]) for (i, j) in sorted(pairs)]    # double-loop order of the reference
     I_v_in = {v: [] for v in vertices}
     I_v_out = {v: [] for v in vertices}
     for e in edges:
@@ -105,6 +116,26 @@ def build_graph(As: Dict[Hashable, np.ndarray], bs: Dict[Hashable, np.ndarray]):
         I_v_out[v].append(e)
         I_v_in[w].append(e)
     return vertices, edges, I_v_in, I_v_out
+
+
+def bounding_box(A, b):
+    """Axis-aligned bounding box (lo, hi) of the bounded polytope A x <= b: exact for boxes, 2n small LPs
+    otherwise."""
+    A = np.asarray(A, float); b = np.asarray(b, float)
+    bx = _as_box(A, b)
+    if bx is not None:
+        return bx
+    from scipy.optimize import linprog
+    n = A.shape[1]
+    lo = np.empty(n); hi = np.empty(n)
+    for k in range(n):
+        c = np.zeros(n); c[k] = 1.0
+        r1 = linprog(c, A_ub=A, b_ub=b, bounds=[(None, None)] * n, method="highs")
+        r2 = linprog(-c, A_ub=A, b_ub=b, bounds=[(None, None)] * n, method="highs")
+        if r1.status != 0 or r2.status != 0:
+            raise ValueError("polytope is empty or unbounded")
+        lo[k], hi[k] = r1.x[k], r2.x[k]
+    return lo, hi
 
 
 def chebyshev_center(A: np.ndarray, b: np.ndarray) -> np.ndarray:
