@@ -9,8 +9,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SRCS = [os.path.join(CSRC, "gcsadmm.hip"), os.path.join(CSRC, "gcsadmm_dims.hip")]
-DEPS = SRCS + [os.path.join(CSRC, f) for f in ("vertex_program.h", "vertex_program.inc", "vertex_kernel.h")] + [
+MAIN = os.path.join(CSRC, "gcsadmm.hip")
+DIMS = os.path.join(CSRC, "gcsadmm_dims.hip")
+# (source, object name, extra flags): the n = 3 / 6 kernels are one object per (dimension, state type)
+UNITS = [(MAIN, "gcsadmm.o", [])] + [(DIMS, f"gcsadmm_n{n}_f{32 if f else 64}.o", [f"-DGCS_DIM={n}", f"-DGCS_F32={f}"])
+                                     for n in (6, 3) for f in (0, 1)]
+DEPS = [MAIN, DIMS] + [os.path.join(CSRC, f) for f in ("vertex_program.h", "vertex_program.inc", "vertex_kernel.h")] + [
     os.path.join(ROOT, "include", "gcsadmm.h")]
 OUT = os.path.join(HERE, "libgcsadmm.so")
 
@@ -23,21 +27,21 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Two translation units compiled concurrently (the n = 3 / 6 instantiations take minutes), then linked."""
+    """Five objects compiled concurrently (the n = 6 instantiations take over a minute each), then linked."""
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if verbose:
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
     objs, procs = [], []
-    for src in SRCS:
-        obj = os.path.join(HERE, os.path.basename(src).replace(".hip", ".o"))
+    for src, name, extra in UNITS:
+        obj = os.path.join(HERE, name)
         objs.append(obj)
         if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in DEPS):
-            procs.append((src, subprocess.Popen([hipcc()] + flags + ["-c", src, "-o", obj])))
-    for src, p in procs:
+            procs.append((name, subprocess.Popen([hipcc()] + flags + extra + ["-c", src, "-o", obj])))
+    for name, p in procs:
         if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
+            raise RuntimeError(f"hipcc failed on {name}")
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT])
     return OUT
 

@@ -249,8 +249,12 @@ template <class PROG, int N, class T> static void launch_vertex_prog(const Verte
 template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &d, hipStream_t s)
 {
     if (d.n_waves > 0) {
-        if (N == 2 && d.all_m4) launch_vertex_prog<ProgM4, N, T>(d, s);
-        else launch_vertex_prog<ProgGeneric, N, T>(d, s);
+        if constexpr (N == 2) {     // the m = 4 program exists for n = 2 only
+            if (d.all_m4) launch_vertex_prog<ProgM4, N, T>(d, s);
+            else launch_vertex_prog<ProgGeneric, N, T>(d, s);
+        } else {
+            launch_vertex_prog<ProgGeneric, N, T>(d, s);
+        }
     }
     if (d.n_special > 0) {
         SpecialArgs<T> a;
@@ -264,12 +268,32 @@ template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &
 
 template <int N, class T> static hipError_t set_lds_attr(bool all_m4, int lds_bytes)
 {
-    const void *fn = (N == 2 && all_m4) ? (const void *)vertex_kernel<ProgM4, N, T> : (const void *)vertex_kernel<ProgGeneric, N, T>;
+    const void *fn = (const void *)vertex_kernel<ProgGeneric, N, T>;
+    if constexpr (N == 2) {
+        if (all_m4) fn = (const void *)vertex_kernel<ProgM4, N, T>;
+    }
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
 
 } // namespace gcsadmm_k
 
-// implemented in gcsadmm_dims.hip (n = 3, 6)
-void gcsadmm_launch_vertex_hi(int n, int dtype, const gcsadmm_k::VertexLaunchDesc &d, hipStream_t s);
-hipError_t gcsadmm_lds_attr_hi(int n, int dtype, int lds_bytes);
+// implemented in gcsadmm_dims.hip, one object per (dimension, state type)
+void gcsadmm_launch_vertex_n3_f32_0(const gcsadmm_k::VertexLaunchDesc &d, hipStream_t s);
+void gcsadmm_launch_vertex_n3_f32_1(const gcsadmm_k::VertexLaunchDesc &d, hipStream_t s);
+void gcsadmm_launch_vertex_n6_f32_0(const gcsadmm_k::VertexLaunchDesc &d, hipStream_t s);
+void gcsadmm_launch_vertex_n6_f32_1(const gcsadmm_k::VertexLaunchDesc &d, hipStream_t s);
+hipError_t gcsadmm_lds_attr_n3_f32_0(int lds_bytes);
+hipError_t gcsadmm_lds_attr_n3_f32_1(int lds_bytes);
+hipError_t gcsadmm_lds_attr_n6_f32_0(int lds_bytes);
+hipError_t gcsadmm_lds_attr_n6_f32_1(int lds_bytes);
+
+static inline void gcsadmm_launch_vertex_hi(int n, int dtype, const gcsadmm_k::VertexLaunchDesc &d, hipStream_t s)
+{
+    if (n == 3) { if (dtype == GCSADMM_F64) gcsadmm_launch_vertex_n3_f32_0(d, s); else gcsadmm_launch_vertex_n3_f32_1(d, s); }
+    else        { if (dtype == GCSADMM_F64) gcsadmm_launch_vertex_n6_f32_0(d, s); else gcsadmm_launch_vertex_n6_f32_1(d, s); }
+}
+static inline hipError_t gcsadmm_lds_attr_hi(int n, int dtype, int lds_bytes)
+{
+    if (n == 3) return dtype == GCSADMM_F64 ? gcsadmm_lds_attr_n3_f32_0(lds_bytes) : gcsadmm_lds_attr_n3_f32_1(lds_bytes);
+    return dtype == GCSADMM_F64 ? gcsadmm_lds_attr_n6_f32_0(lds_bytes) : gcsadmm_lds_attr_n6_f32_1(lds_bytes);
+}
