@@ -22,3 +22,26 @@ def oracle_lib():
 
 BENCHMARKS = ["benchmark1", "benchmark2", "benchmark3", "benchmark4"]
 SMALL = ["test1", "test2", "test3", "test_autogen1", "test_autogen2"]
+
+
+def star_case(k=24, seed=0):
+    """One large box overlapping k small boxes (degree 2k), with s and t inside two of the small ones:
+    exercises high-degree vertices (several shuffle steps per reduction, wide lane groups)."""
+    import numpy as np
+    from gcs_admm_amd.graph import convert_pt_to_polytope
+    rng = np.random.default_rng(seed)
+    A = np.vstack([np.eye(2), -np.eye(2)])
+    As, bs = {}, {}
+    s = np.array([-4.0, 0.0]); t = np.array([4.0, 0.3])
+    As['s'], bs['s'] = convert_pt_to_polytope(s)
+    As['t'], bs['t'] = convert_pt_to_polytope(t)
+    As[0], bs[0] = A, np.array([3.0, 3.0, 3.0, 3.0])            # the hub [-3,3]^2
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    for i, a in enumerate(ang):
+        c = 3.2 * np.array([np.cos(a), np.sin(a)]) + rng.uniform(-0.05, 0.05, 2)
+        h = np.array([0.45, 0.45])
+        As[i + 1], bs[i + 1] = A, np.hstack([c + h, -(c - h)])
+    # two more boxes holding s and t and touching the ring
+    As[k + 1], bs[k + 1] = A, np.hstack([s + 1.0, -(s - 1.0)])
+    As[k + 2], bs[k + 2] = A, np.hstack([t + 1.0, -(t - 1.0)])
+    return As, bs, 2

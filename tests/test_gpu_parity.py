@@ -247,3 +247,24 @@ def test_lattice_10k_trace_against_oracle(torch_gpu, oracle_lib):
     d32 = _solver(g, "f32")
     r32 = d32.solve(max_it=60, eps_abs=0.0, eps_rel=0.0)
     assert np.max(np.abs(r32["pri_res_seq"][1:] - res["pri_res_seq"][1:]) / res["pri_res_seq"][1:]) <= 1e-4
+
+
+def test_high_degree_vertex_and_degree_limit(torch_gpu, oracle_lib):
+    from conftest import star_case
+    from gcs_admm_amd.graph import graph_from_sets
+    from gcs_admm_amd import solver
+    As, bs, n = star_case(24)
+    g = graph_from_sets(As, bs, n)
+    assert np.diff(g.inc_ptr).max() >= 40
+    d = _solver(g)
+    res = d.solve(max_it=80, eps_abs=0.0, eps_rel=0.0)
+    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=80, eps_abs=0.0, eps_rel=0.0)
+    assert res["inner_failures"] == 0
+    for key in ("pri_res_seq", "dual_res_seq"):
+        assert np.all(np.abs(res[key] - ora[key]) <= 2e-4 + 1e-3 * np.abs(ora[key])), key
+    # more than 63 incident edges at one vertex is refused with a documented code, not a crash
+    As, bs, n = star_case(40)
+    g2 = graph_from_sets(As, bs, n)
+    assert np.diff(g2.inc_ptr).max() > 63
+    with pytest.raises(solver.GcsAdmmError, match="degree"):
+        _solver(g2)

@@ -98,3 +98,20 @@ def test_emulated_wave_program_other_dimensions(emu, oracle_lib, n):
             mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
         assert np.abs(copy[:, mask] - o.copy[:, mask]).max() <= 2e-3
         o.edge_step(1.0)
+
+
+def test_emulated_wave_program_high_degree(emu, oracle_lib):
+    from conftest import star_case
+    from gcs_admm_amd.graph import graph_from_sets
+    As, bs, n = star_case(24)
+    g = graph_from_sets(As, bs, n)
+    assert np.diff(g.inc_ptr).max() >= 40
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    for it in range(10):
+        copy, xv, zv, yv, cnt, gen = emu_step(emu, g, o.zedge.copy(), o.mu.copy(), 1.0, 1.0)
+        assert cnt[0] == 0 and o.vertex_step(1.0, 1.0) == 0
+        mask = np.zeros(2 * g.num_edges, bool)
+        for v in np.nonzero(gen)[0]:
+            mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
+        assert np.abs(copy[:, mask] - o.copy[:, mask]).max() <= 2e-3
+        o.edge_step(1.0)
