@@ -1,0 +1,34 @@
+"""Driver of tools/sanitize_cpu.sh (expects /tmp/libemu_asan.so and /tmp/libo_asan.so)."""
+import sys, ctypes as C, numpy as np
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from gcs_admm_amd.cases import load_fixture
+from gcs_admm_amd.graph import lattice_boxes, graph_from_sets
+from conftest import star_case
+from oracle.oracle import Oracle
+lib=C.CDLL('/tmp/libemu_asan.so')
+def p(a): return a.ctypes.data_as(C.c_void_p)
+def step(fn,g,z,m):
+    c=g.c; NI=2*g.num_edges
+    copy=np.zeros((c,NI)); xv=np.zeros((g.num_vertices,2*g.n)); zv=np.zeros_like(xv); yv=np.zeros(g.num_vertices)
+    cnt=np.zeros(2,dtype=np.int32); gen=np.zeros(g.num_vertices,dtype=np.int32)
+    r=getattr(lib,fn)(g.n,g.num_vertices,g.num_edges,NI,p(g.inc_ptr),p(g.inc_edge),p(g.inc_out),p(g.poly_ptr),p(g.poly_A),p(g.poly_b),p(g.interior),g.src,g.dst,p(z),p(m),C.c_double(1.0),C.c_double(1.0),C.c_double(1e-4),C.c_double(1e-9),60,p(copy),p(xv),p(zv),p(yv),p(cnt),p(gen))
+    assert r==0
+graphs=[('benchmark4',load_fixture('benchmark4')[1],'emu_vertex_step'),('benchmark3',load_fixture('benchmark3')[1],'emu_vertex_step'),
+        ('lattice m4',lattice_boxes(9,7,seed=1),'emu_vertex_step_m4'),('lattice n6',lattice_boxes(5,4,n=6,seed=1),'emu_vertex_step'),
+        ('star',graph_from_sets(*star_case(24)),'emu_vertex_step')]
+for name,g,fn in graphs:
+    o=Oracle(g,ipm_tol=1e-9)
+    for it in range(6):
+        step(fn,g,o.zedge.copy(),o.mu.copy()); o.vertex_step(1.0,1.0,1); o.edge_step(1.0)
+    print(name,'ok')
+
+# ---- oracle under the sanitizers
+import oracle.oracle as O
+O._lib=C.CDLL('/tmp/libo_asan.so'); O._lib.oracle_compute_cost.restype=C.c_double
+from gcs_admm_amd.cases import load_fixture
+from gcs_admm_amd.graph import lattice_boxes
+for name in ('benchmark1','benchmark4'):
+    case,g=load_fixture(name); r=O.Oracle(g,ipm_tol=1e-9).run(nthreads=2); print(name,r['iterations'])
+g=lattice_boxes(5,4,n=6,seed=1); r=O.Oracle(g,ipm_tol=1e-9).run(max_it=5,eps_abs=0,eps_rel=0,nthreads=2); print('n6',r['iterations'])
