@@ -131,7 +131,8 @@ class DeviceSolver:
         self.h = h
         c, E, V, n = g.c, g.num_edges, g.num_vertices, g.n
         z = lambda *s, dt=self.tdtype: torch.zeros(*s, dtype=dt, device=self.device)
-        self.copy, self.mu, self.zedge = z(c, self.NI), z(c, self.NI), z(c, E)
+        # (at least one column each: an empty tensor has a null data pointer, which the ABI rejects)
+        self.copy, self.mu, self.zedge = z(c, max(self.NI, 1)), z(c, max(self.NI, 1)), z(c, max(E, 1))
         self.xv, self.zv, self.yv = z(V, 2 * n, dt=torch.float64), z(V, 2 * n, dt=torch.float64), z(V, dt=torch.float64)
         self.sums = z(5, dt=torch.float64)
         self._cost = z(1, dt=torch.float64)

@@ -268,3 +268,27 @@ def test_high_degree_vertex_and_degree_limit(torch_gpu, oracle_lib):
     assert np.diff(g2.inc_ptr).max() > 63
     with pytest.raises(solver.GcsAdmmError, match="degree"):
         _solver(g2)
+
+
+def test_degenerate_graphs(torch_gpu, oracle_lib):
+    """no edges at all; s and t in regions that do not touch (no s-t path): defined behaviour, no crash"""
+    from gcs_admm_amd.graph import convert_pt_to_polytope, graph_from_sets
+    A = np.vstack([np.eye(2), -np.eye(2)])
+    As = {}; bs = {}
+    As['s'], bs['s'] = convert_pt_to_polytope(np.array([0.0, 0.0]))
+    As['t'], bs['t'] = convert_pt_to_polytope(np.array([5.0, 0.0]))
+    g = graph_from_sets(As, bs, 2)
+    assert g.num_edges == 0
+    res = _solver(g).solve(max_it=30)
+    ora0 = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=30)
+    # nmu = 0 makes eps_dual = 0 and the strict test `dual < eps_dual` (admm_solver_v3.py:712) can never pass
+    assert res["status"] == "max_it" and res["iterations"] == ora0["iterations"] == 31 and res["cost"] == 0.0
+    As[0], bs[0] = A, np.array([1.0, 1.0, 1.0, 1.0])          # holds s
+    As[1], bs[1] = A, np.array([6.0, 1.0, -4.0, 1.0])         # holds t, disjoint from region 0
+    g = graph_from_sets(As, bs, 2)
+    d = _solver(g)
+    res = d.solve(max_it=200)
+    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=200)
+    assert res["iterations"] == ora["iterations"] and res["status"] in ("converged", "max_it")
+    assert np.isfinite(res["pri_res_seq"]).all() and np.isfinite(d.copy.cpu().numpy()).all()
+    assert np.all(np.abs(res["pri_res_seq"] - ora["pri_res_seq"]) <= 2e-4 + 1e-3 * np.abs(ora["pri_res_seq"]))
