@@ -19,6 +19,20 @@
 #include <vector>
 
 #include "gcsadmm.h"
+#ifdef GCS_PHASE_TIMING
+// diagnostic build: sub-phase stamps inside the border factorisation (lane 0 of each wavefront)
+__device__ unsigned long long g_sub_cycles[16];
+__device__ __forceinline__ void gcs_stamp(int k)
+{
+    static __shared__ unsigned long long last;
+    if (threadIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (k > 0) atomicAdd(&g_sub_cycles[k], t - last);
+        last = t;
+    }
+}
+#define GCS_STAMP(k) gcs_stamp(k)
+#endif
 #include "vertex_kernel.h"
 
 namespace {
@@ -534,6 +548,11 @@ gcsadmm_status gcsadmm_cost(gcsadmm_handle h, const gcsadmm_state *st, double ep
 }
 
 #ifdef GCS_PHASE_TIMING
+int gcsadmm_debug_sub_cycles(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sub_cycles), 16 * sizeof(unsigned long long));
+}
+
 int gcsadmm_debug_phase_cycles(unsigned long long *out64)
 {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_cycles), 64 * sizeof(unsigned long long));

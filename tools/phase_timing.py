@@ -24,3 +24,11 @@ for wl in ("s10k", "benchmark4"):
     print(wl, "total wave-cycles (s_memtime ticks) over 20 steps: %.3e" % tot)
     for i, n in enumerate(names):
         print("  %-28s %6.2f %%" % (n, 100 * cyc[i] / tot))
+    sub = (C.c_ulonglong * 16)()
+    d.lib.gcsadmm_debug_sub_cycles(sub)
+    sv = np.array(list(sub), dtype=np.float64)
+    if sv.sum() > 0:
+        lab = ["", "gap/mu/convergence", "cone scaling, W^-2", "sides: chol5, inverse, Y", "assemble M", "change of variables + Su", "chol9", "store factor", "affine solve"]
+        print("  inside border_factor (lane 0 of each wavefront, cumulative since start):")
+        for k in range(1, 8):
+            print("    %-28s %6.2f %%" % (lab[k + 1] if k + 1 < len(lab) else k, 100 * sv[k] / sv[1:8].sum()))
