@@ -127,6 +127,12 @@ def main():
                            "waves": q["num_waves"], "lds_bytes_per_wave": q["lds_bytes"],
                            "inner_iters_last_step_total": dev.read_control().inner_iters,
                            "special_vertices": q["num_special"]}
+        # the streaming half of the iteration on its own (edge average + dual + residual sums + control,
+        # 14 c |E| words), HBM-bound once the state outgrows the caches
+        edge_bytes = 14.0 * g.c * g.num_edges * wb
+        out["roofline_edge"] = {"bound": "hbm", "achieved": edge_bytes / (e_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": edge_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "edge_kernel+finalize+control",
+                                "avg_step_ms": e_ms, "algorithmic_bytes_per_step": edge_bytes}
         # ---- matched convergence: the reference's own stop rule ----
         if args.workload == "benchmark4":
             res = dev.solve()

@@ -25,11 +25,13 @@ __device__ unsigned long long g_sub_cycles[16];
 __device__ __forceinline__ void gcs_stamp(int k)
 {
     static __shared__ unsigned long long last;
+    __builtin_amdgcn_sched_barrier(0);
     if (threadIdx.x == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         if (k > 0) atomicAdd(&g_sub_cycles[k], t - last);
         last = t;
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 #define GCS_STAMP(k) gcs_stamp(k)
 #endif
@@ -370,6 +372,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         }
         const int want = std::max(1, (n_generic + 1023) / 1024);
         slots_cap = std::min(slots_cap, want);
+        if (const char *ov = getenv("GCSADMM_SLOTS")) slots_cap = std::max(1, std::min(slots_cap > 0 ? MAX_SLOTS : 1, atoi(ov)));
     }
     int lanes = 0, slots = 0, max_slots_used = 0;
     for (int v = 0; v < V; ++v) {

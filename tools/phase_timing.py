@@ -28,7 +28,7 @@ for wl in ("s10k", "benchmark4"):
     d.lib.gcsadmm_debug_sub_cycles(sub)
     sv = np.array(list(sub), dtype=np.float64)
     if sv.sum() > 0:
-        lab = ["", "gap/mu/convergence", "cone scaling, W^-2", "sides: chol5, inverse, Y", "assemble M", "change of variables + Su", "chol9", "store factor", "affine solve"]
+        lab = ["", "cone scaling, W^-2", "sides: chol5, inverse, Y", "M: x-x block", "M: zeta-x, zeta-zeta, Su", "change of variables", "chol9", "store factor", "both solves: rhs + side products", "both solves: chol_solve + t", "affine solve: dnu + stores", "corrector solve: dnu + stores"]
         print("  inside border_factor (lane 0 of each wavefront, cumulative since start):")
-        for k in range(1, 8):
-            print("    %-28s %6.2f %%" % (lab[k + 1] if k + 1 < len(lab) else k, 100 * sv[k] / sv[1:8].sum()))
+        for k in range(1, 12):
+            print("    %-28s %6.2f %%" % (lab[k], 100 * sv[k] / sv[1:12].sum()))
