@@ -25,7 +25,8 @@ def emu():
     src = os.path.join(HERE, "hostemu", "emu.cpp")
     out = os.path.join(HERE, "hostemu", "libemu.so")
     hdr = os.path.join(ROOT, "gcs_admm_amd", "csrc", "vertex_program.h")
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [src, hdr, os.path.join(os.path.dirname(hdr), "vertex_program.inc")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.dirname(hdr), src, "-o", out])
     return C.CDLL(out)
 
