@@ -896,6 +896,10 @@ int oracle_solve_vertex(int n, int m, const double *A, const double *b_raw, cons
 /* ------------------------------------------------------------------ vertex step over the whole graph
  * (admm_solver_v3.py:469-540).  targets = zedge - mu_scale * mu.  Returns the number of
  * sub-problems whose inner solver did not converge; ipm_iters_total accumulates iterations. */
+/* diagnostics: when set, oracle_vertex_step records the Newton iteration count of every vertex (-1 = failed) */
+static int *g_iters_out = 0;
+void oracle_set_iters_out(int *buf) { g_iters_out = buf; }
+
 int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double *mu, double mu_scale,
                        double rho, const oracle_inner_params *ip, double *copy,
                        double *xv, double *zv, double *yv, long *ipm_iters_total, int nthreads)
@@ -922,6 +926,7 @@ int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double 
                                     d, d_in, v == G->src, v == G->dst, T, rho, ip, C,
                                     xv + (size_t)v * 2 * n, zv + (size_t)v * 2 * n, yv + v);
         if (r < 0) fails += 1; else iters += r;
+        if (g_iters_out) g_iters_out[v] = r;
         for (int k = 0; k < d; ++k)
             for (int w = 0; w < c; ++w) copy[w * NI + lo + k] = C[w * d + k];
         if (T != Tst) free(T);
