@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="benchmark4", choices=["benchmark4", "s10k", "s100k", "s6d"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--loop-only", action="store_true",
+                    help="only the timed loop and the per-kernel timing (no convergence runs, no CPU baseline): the "
+                         "command to put under rocprofv3, so that its per-kernel averages cover the same launches as roofline.avg_launch_ms")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -101,7 +104,7 @@ def main():
         ach = alg_bytes / (v_ms * 1e-3) / 1e9
         q = dev.query()
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01", "s10k_f32state_hbm_counters_v3.json")
+        prof = os.path.join(ROOT, "profiles", "r01", "s10k_f32state_hbm_counters_v4.json")
         if args.workload == "s10k" and os.path.exists(prof):
             # PMC counters cannot be read from inside this process: the per-launch figure is the one rocprofv3
             # collected for this same command line (separate --pmc passes, profiles/r01), FETCH_SIZE doubled
@@ -134,7 +137,7 @@ def main():
                                 "frac": edge_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "edge_kernel+finalize+control",
                                 "avg_step_ms": e_ms, "algorithmic_bytes_per_step": edge_bytes}
         # ---- matched convergence: the reference's own stop rule ----
-        if args.workload == "benchmark4":
+        if args.workload == "benchmark4" and not args.loop_only:
             res = dev.solve()
             gold = extra["case"]["golden_v3"]
             out["convergence"] = {"iterations_to_stop": res["iterations"], "reference_iterations": gold["iterations"],
@@ -148,7 +151,7 @@ def main():
                                    "cost": tight["cost"], "rel_gap_to_classic": abs(tight["cost"] - classic) / classic}
             out["reference_published"] = {"its_per_sec": REF_PUBLISHED_ITS, "note": "465 it / 37.88 s solver-time-only, hardware unknown (BASELINE.md)"}
         # ---- CPU baseline: the oracle on the host cores, bounded sample ----
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not args.loop_only and world == 1:
             from oracle.oracle import Oracle
             ncpu = os.cpu_count() or 1
             # thread count: the best of a short sweep (OpenMP over vertices; more threads than vertices, or

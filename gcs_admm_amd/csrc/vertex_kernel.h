@@ -96,7 +96,7 @@ struct ProgGeneric {   // any facet count per polytope, facet-row duals in LDS
     template <int N> using LaneT = gcs::Lane<N>;
     template <class T> using Args = gcs::VertexArgs<T>;
     using Shared = gcs::WaveShared;
-    static constexpr bool lds_duals = true;
+    static __device__ __forceinline__ void shared_init(Shared &S, double *smem, int n, int mm) { gcs::wave_shared_init(S, smem, n, mm); }
     template <int N, class T, class EX>
     static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
     {
@@ -107,7 +107,7 @@ struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet lo
     template <int N> using LaneT = gcs_m4::Lane<N>;
     template <class T> using Args = gcs_m4::VertexArgs<T>;
     using Shared = gcs_m4::WaveShared;
-    static constexpr bool lds_duals = false;
+    static __device__ __forceinline__ void shared_init(Shared &S, double *smem, int n, int mm) { gcs_m4::wave_shared_init(S, smem, n, mm); }
     template <int N, class T, class EX>
     static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
     {
@@ -122,11 +122,7 @@ __global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Ar
     if (cb->status != GCSADMM_RUNNING) return;
     const double rho = cb->rho, mu_scale = cb->mu_scale;
     typename PROG::Shared S;
-    S.MM = a.MM;
-    const int dual_rows = PROG::lds_duals ? 2 * a.MM : 0;
-    S.lamA = smem;
-    S.lamB = S.lamA + dual_rows * WAVE;
-    S.slots = S.lamB + dual_rows * WAVE;
+    PROG::shared_init(S, smem, N, a.MM);
     using LaneT = typename PROG::template LaneT<N>;
     LaneT L;
 #ifdef GCS_PHASE_TIMING

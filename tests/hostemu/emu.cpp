@@ -82,9 +82,7 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
         for (int w = 0; w < n_waves; ++w) {
             std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
             WaveShared S;
-            const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
-            S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
-            S.slots = S.lamB + dual_rows * WAVE;
+            wave_shared_init(S, smem.data(), n, MM);
             run_vertex_program<NN, double>(*ex, w, a, S, rho, mu_scale);
         }
         delete ex;
@@ -168,9 +166,7 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
         for (int w = 0; w < n_waves; ++w) {
             std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
             WaveShared S;
-            const int dual_rows = FIXED_FACETS ? 0 : 2 * MM;
-            S.MM = MM; S.lamA = smem.data(); S.lamB = S.lamA + dual_rows * WAVE;
-            S.slots = S.lamB + dual_rows * WAVE;
+            wave_shared_init(S, smem.data(), n, MM);
             run_vertex_program<NN, double>(*ex, w, a, S, rho, mu_scale);
         }
         delete ex;
