@@ -91,7 +91,10 @@ def main():
            "dtype": "f64", "data": "synthetic" if args.workload != "benchmark4" else "fixture of the reference's test_data/benchmark4.py",
            "config": {"workload": args.workload, "V": g.num_vertices, "E": g.num_edges, "n": g.n,
                       "state_dtype": dtype, "inner_arithmetic": "f64", "ipm_tol": 1e-9,
-                      "parallelism": f"{world} replica(s)"}}
+                      "parallelism": f"{world} replica(s)",
+                      "seed": None if args.workload == "benchmark4" else 0,
+                      "degree_histogram": {int(k): int(v) for k, v in zip(*np.unique(np.diff(g.inc_ptr), return_counts=True))},
+                      "facets_histogram": {int(k): int(v) for k, v in zip(*np.unique(np.diff(g.poly_ptr), return_counts=True))}}}
     if rank == 0:
         # ---- roofline of the dominant kernel (vertex step), measured with HIP events on its stream ----
         dev.reset(**params)
