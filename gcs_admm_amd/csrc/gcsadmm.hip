@@ -362,6 +362,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     int slots_cap = MAX_SLOTS;
     while (slots_cap > 1 && lds_need(slots_cap) > 160 * 1024) --slots_cap;
     if (lds_need(slots_cap) > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
+    const int lds_cap = slots_cap;
     // small graphs: spread the vertices over more wavefronts (a wavefront runs as long as its slowest
     // vertex, and the chip has 1024 one-wave-per-SIMD slots to fill before packing pays)
     {
@@ -372,7 +373,8 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         }
         const int want = std::max(1, (n_generic + 1023) / 1024);
         slots_cap = std::min(slots_cap, want);
-        if (const char *ov = getenv("GCSADMM_SLOTS")) slots_cap = std::max(1, std::min(slots_cap > 0 ? MAX_SLOTS : 1, atoi(ov)));
+        // tuning knob: vertices per wavefront (still bounded by the LDS limit found above)
+        if (const char *ov = getenv("GCSADMM_SLOTS")) slots_cap = std::max(1, std::min(lds_cap, atoi(ov)));
     }
     int lanes = 0, slots = 0, max_slots_used = 0;
     for (int v = 0; v < V; ++v) {
