@@ -14,8 +14,11 @@ DIMS = os.path.join(CSRC, "gcsadmm_dims.hip")
 # (source, object name, extra flags): the n = 3 / 6 kernels are one object per (dimension, state type)
 UNITS = [(MAIN, "gcsadmm.o", [])] + [(DIMS, f"gcsadmm_n{n}_f{32 if f else 64}.o", [f"-DGCS_DIM={n}", f"-DGCS_F32={f}"])
                                      for n in (6, 3) for f in (0, 1)]
-DEPS = [MAIN, DIMS] + [os.path.join(CSRC, f) for f in ("vertex_program.h", "vertex_program.inc", "vertex_kernel.h")] + [
-    os.path.join(ROOT, "include", "gcsadmm.h")]
+LP = os.path.join(CSRC, "polytope_lp.hip")      # batched tiny LPs for graph construction (own object, own dependencies)
+UNITS.append((LP, "polytope_lp.o", []))
+HDR = os.path.join(ROOT, "include", "gcsadmm.h")
+DEPS = [MAIN, DIMS] + [os.path.join(CSRC, f) for f in ("vertex_program.h", "vertex_program.inc", "vertex_kernel.h")] + [HDR]
+UNIT_DEPS = {LP: [LP, HDR]}
 OUT = os.path.join(HERE, "libgcsadmm.so")
 
 
@@ -27,8 +30,8 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Five objects compiled concurrently (the n = 6 instantiations take over a minute each), then linked."""
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    """Six objects compiled concurrently (the n = 6 instantiations take over a minute each), then linked."""
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + [LP]):
         return OUT
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if verbose:
@@ -37,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, name, extra in UNITS:
         obj = os.path.join(HERE, name)
         objs.append(obj)
-        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in DEPS):
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in UNIT_DEPS.get(src, DEPS)):
             procs.append((name, subprocess.Popen([hipcc()] + flags + extra + ["-c", src, "-o", obj])))
     for name, p in procs:
         if p.wait() != 0:

@@ -25,7 +25,9 @@ STATUS_NAME = {RUNNING: "running", CONVERGED: "converged", MAX_IT: "max_it", DIV
 
 EXPORTS = ["gcsadmm_create", "gcsadmm_destroy", "gcsadmm_last_error", "gcsadmm_reset", "gcsadmm_vertex_step",
            "gcsadmm_edge_step", "gcsadmm_control", "gcsadmm_run", "gcsadmm_run_timed", "gcsadmm_read_control",
-           "gcsadmm_cost", "gcsadmm_query"]
+           "gcsadmm_cost", "gcsadmm_query",
+           # graph construction at scale (gcs_admm_amd/scene.py)
+           "gcsadmm_polytope_last_error", "gcsadmm_polytope_centers", "gcsadmm_polytope_bounds", "gcsadmm_polytope_overlaps"]
 
 
 class GraphDesc(C.Structure):

@@ -158,6 +158,35 @@ gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int3
                                  void *stream, float *vertex_ms, int32_t *vertex_launches,
                                  float *edge_ms, int32_t *edge_launches);
 
+/* ---------------------------------------------------------------------------------------------
+ * Graph construction at scale.  The reference decides every ordered pair of
+ * regions with one LP feasibility solve through Drake/MOSEK (utils.py:31-82 build_graph, :49-65
+ * check_overlap); these entry points run the same decisions as batches of tiny LPs on the device, one LP
+ * per lane (polytope_lp.hip).  All pointers are HOST pointers (set-up code, called once per scene); the
+ * polytope CSR is the one of gcsadmm_graph_desc (rows of region p: poly_ptr[p] .. poly_ptr[p+1]).
+ * n = 1..6.  Return value: gcsadmm_status; text of the last failure: gcsadmm_polytope_last_error().
+ * Optional `status` arrays receive the LP status per problem: 0 converged, 1 / 2 decided early
+ * (overlap / separation proven), -1 iteration limit.
+ */
+const char *gcsadmm_polytope_last_error(void);
+
+/* Chebyshev centre (centre of the largest inscribed ball) and its radius for every region: the strictly
+ * interior point the vertex kernel centres a sub-problem on (graph.py chebyshev_center on the host).
+ * centers[P][n], radii[P] (may be NULL; capped at 1e6 for unbounded sets; <= 0: no interior). */
+int gcsadmm_polytope_centers(int n, int num_polytopes, const int *poly_ptr, const double *poly_A, const double *poly_b,
+                             int device, double *centers, double *radii, int *status);
+
+/* Axis-aligned bounding box of every region (2n LPs each, started from `centers`); lo[P][n], hi[P][n];
+ * unbounded directions come back near +-1e8. */
+int gcsadmm_polytope_bounds(int n, int num_polytopes, const int *poly_ptr, const double *poly_A, const double *poly_b,
+                            const double *centers, int device, double *lo, double *hi, int *status);
+
+/* overlap[t] = 1 iff regions pair_a[t] and pair_b[t] share a point (closed sets; inscribed radius of the
+ * intersection >= -tol), the decision of utils.py:49-65.  `centers` (may be NULL) only supplies start points. */
+int gcsadmm_polytope_overlaps(int n, int num_polytopes, const int *poly_ptr, const double *poly_A, const double *poly_b,
+                              const double *centers, long num_pairs, const int *pair_a, const int *pair_b, double tol,
+                              int device, unsigned char *overlap, int *status);
+
 #ifdef __cplusplus
 }
 #endif

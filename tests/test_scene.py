@@ -1,0 +1,150 @@
+"""Graph construction at scale: the oracle's LP decisions against the committed
+edge lists (CPU), the sort-and-sweep broad phase against brute force (CPU), and the device LPs
+(csrc/polytope_lp.hip through the C ABI) against the oracle and the fixtures (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import BENCHMARKS, SMALL
+from gcs_admm_amd.cases import fixture_sets, load_fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import polytope_oracle as PO   # noqa: E402
+
+
+def random_polytope(rng, n, m, centre, scale):
+    """m random half-spaces at distance ~scale around `centre` plus a bounding box (always bounded)."""
+    A = rng.normal(size=(m, n)); A /= np.linalg.norm(A, axis=1)[:, None]
+    b = A @ centre + scale * rng.uniform(0.3, 1.0, size=m)
+    A = np.vstack([A, np.eye(n), -np.eye(n)])
+    b = np.hstack([b, centre + 2 * scale, -(centre - 2 * scale)])
+    return A, b
+
+
+# ------------------------------------------------------------------------------------------- CPU
+@pytest.mark.parametrize("name", ["test1", "test2", "test3", "test_autogen1", "benchmark1", "benchmark2"])
+def test_oracle_edges_match_fixture(name):
+    """LP feasibility per ordered pair in double-loop order (utils.py:31-82) gives the committed edge list"""
+    case, _ = load_fixture(name)
+    As, bs, n, _, _ = fixture_sets(name)
+    assert [list(e) for e in PO.edges(As, bs)] == case["edges"]
+
+
+def test_candidate_pairs_against_brute_force():
+    from gcs_admm_amd.scene import candidate_pairs
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 4):
+        c = rng.uniform(0, 8, (250, n)); w = rng.uniform(0.05, 0.9, (250, n))
+        lo, hi = c - w, c + w
+        a, b = candidate_pairs(lo, hi, 0.0)
+        ref = {(i, j) for i in range(250) for j in range(i + 1, 250) if np.all(lo[i] <= hi[j]) and np.all(lo[j] <= hi[i])}
+        assert set(zip(a.tolist(), b.tolist())) == ref and len(a) == len(ref)
+    a, b = candidate_pairs(np.zeros((1, 2)), np.ones((1, 2)))
+    assert len(a) == 0
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + BENCHMARKS)
+def test_device_graph_matches_fixture(name):
+    """edges (order included) and CSR of the device-built graph equal the committed fixture; the interior
+    points are the Chebyshev centres (same radius as the oracle's LP)"""
+    from gcs_admm_amd.scene import PolytopeScene, build_graph_device, graph_from_sets_device
+    case, gref = load_fixture(name)
+    As, bs, n, _, _ = fixture_sets(name)
+    V, E, I_in, I_out, cen = build_graph_device(As, bs)
+    assert V == case["keys"] and [list(e) for e in E] == case["edges"]
+    g = graph_from_sets_device(As, bs, n)
+    for f in ("inc_ptr", "inc_edge", "inc_out", "edge_inc_tail", "edge_inc_head", "poly_ptr"):
+        assert np.array_equal(getattr(g, f), getattr(gref, f)), f
+    scene = PolytopeScene([(As[k], bs[k]) for k in V])
+    cen, rad, st = scene.centers()
+    lo, hi, _ = scene.bounds(cen)
+    for i, k in enumerate(V):
+        xo, ro = PO.chebyshev(As[k], bs[k])
+        assert abs(rad[i] - ro) <= 1e-8 * max(1.0, abs(ro)), (k, rad[i], ro)
+        slack = (bs[k] - As[k] @ cen[i]) / np.linalg.norm(As[k], axis=1)
+        assert slack.min() >= rad[i] - 1e-7                      # the returned point has that ball around it
+        lo_o, hi_o = PO.bounding_box(As[k], bs[k])
+        assert np.allclose(lo[i], lo_o, atol=1e-6) and np.allclose(hi[i], hi_o, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 6])
+def test_device_overlaps_random_polytopes(n):
+    """pairwise decisions on random polytopes equal the oracle's wherever the decision has a margin"""
+    from gcs_admm_amd.scene import PolytopeScene
+    rng = np.random.default_rng(10 + n)
+    P = 60
+    polys = [random_polytope(rng, n, 4 + n, rng.uniform(0, 3.0, n), rng.uniform(0.4, 1.2)) for _ in range(P)]
+    scene = PolytopeScene(polys)
+    cen, rad, _ = scene.centers()
+    assert np.all(rad > 0)
+    pa, pb = np.triu_indices(P, 1)
+    flags, st = scene.overlaps(pa, pb, 1e-9, cen)
+    checked = 0
+    for t, (i, j) in enumerate(zip(pa, pb)):
+        r = PO.overlap_radius(polys[i][0], polys[i][1], polys[j][0], polys[j][1])
+        if abs(r) < 1e-6:
+            continue
+        checked += 1
+        assert bool(flags[t]) == (r > 0), (i, j, r, st[t])
+        assert bool(flags[t]) == PO.overlap(polys[i][0], polys[i][1], polys[j][0], polys[j][1])
+    assert checked > 0.9 * len(pa) and 0 < flags.sum() < len(pa)
+
+
+@pytest.mark.gpu
+def test_device_overlaps_degenerate_cases():
+    """touching boxes overlap (closed sets, as for the reference's feasibility solve), a gap does not; the
+    reference's point vertices (boxes of half-width 1e-6, utils.py:12-28) are found inside their region"""
+    from gcs_admm_amd.graph import convert_pt_to_polytope
+    from gcs_admm_amd.scene import PolytopeScene
+    box = lambda lo, hi: (np.vstack([np.eye(2), -np.eye(2)]), np.hstack([hi, -np.asarray(lo, float)]))
+    polys = [box([0, 0], [1, 1]), box([1, 0], [2, 1]), box([1 + 1e-5, 0], [2, 1]), box([1, 1], [2, 2]),
+             convert_pt_to_polytope(np.array([0.5, 0.5])), convert_pt_to_polytope(np.array([1.5, 3.0])),
+             box([-50, -50], [50, 50])]
+    scene = PolytopeScene(polys)
+    pa = np.array([0, 0, 0, 0, 0, 4, 5, 1], np.int32); pb = np.array([1, 2, 3, 4, 5, 6, 6, 2], np.int32)
+    flags, _ = scene.overlaps(pa, pb)
+    assert flags.tolist() == [1, 0, 1, 1, 0, 1, 1, 1]
+    scene._centers = None                                         # start points at the origin instead of the centres
+    flags0, _ = scene.overlaps(pa, pb, 1e-9, None)
+    assert flags0.tolist() == flags.tolist()
+
+
+@pytest.mark.gpu
+def test_device_graph_lattice_at_scale():
+    """10k-box lattice: the device pipeline (centres, boxes, sweep, LPs) finds exactly the edges the exact
+    interval test finds (graph.lattice_boxes)"""
+    from gcs_admm_amd.graph import lattice_boxes
+    from gcs_admm_amd.scene import graph_from_sets_device
+    gref = lattice_boxes(100, 100, seed=0)
+    As = {k: gref.poly_A[gref.poly_ptr[i]:gref.poly_ptr[i + 1]] for i, k in enumerate(gref.keys)}
+    bs = {k: gref.poly_b[gref.poly_ptr[i]:gref.poly_ptr[i + 1]] for i, k in enumerate(gref.keys)}
+    g = graph_from_sets_device(As, bs, 2)
+    assert g.num_edges == gref.num_edges
+    assert np.array_equal(g.edge_tail, gref.edge_tail) and np.array_equal(g.edge_head, gref.edge_head)
+    # the interior points are Chebyshev centres: not unique for a rectangle (any point of a segment), so compare
+    # the radius of the ball around them with the one around the box midpoints of the generator
+    def ball(gg):
+        r = np.empty(gg.num_vertices)
+        for v in range(gg.num_vertices):
+            A = gg.poly_A[gg.poly_ptr[v]:gg.poly_ptr[v + 1]]; b = gg.poly_b[gg.poly_ptr[v]:gg.poly_ptr[v + 1]]
+            r[v] = ((b - A @ gg.interior[v]) / np.linalg.norm(A, axis=1)).min()
+        return r
+    assert np.allclose(ball(g), ball(gref), atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_device_lp_errors():
+    from gcs_admm_amd.scene import PolytopeScene
+    from gcs_admm_amd.solver import GcsAdmmError
+    A = np.vstack([np.eye(7), -np.eye(7)]); b = np.ones(14)
+    with pytest.raises(GcsAdmmError, match="n = 1..6"):
+        PolytopeScene([(A, b)]).centers()
+    A2 = np.vstack([np.eye(2), -np.eye(2)]); b2 = np.ones(4)
+    with pytest.raises(GcsAdmmError, match="out of range"):
+        PolytopeScene([(A2, b2)]).overlaps([0], [3])
