@@ -64,19 +64,37 @@ template <class LaneT> struct GpuExec {
     }
     // segmented reduction over the consecutive block lanes of one side of a vertex (vertex_program.inc):
     // shuffle-down tree, nsteps is wave-uniform; all 64 lanes execute it, non-contributors pass the identity.
+    template <int SH> static __device__ __forceinline__ double row_down(double x)
+    {
+        // lane i reads lane i + SH of its 16-lane row (DPP row_shl); lanes past the row end read 0 and are masked off
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + SH, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + SH, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    template <int CNT, class SHUF>
+    static __device__ __forceinline__ void seg_step(double (&v)[CNT], bool ok, int special, int op, SHUF &&shuf)
+    {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            const double t = shuf(v[k]);
+            if (k == special && op == 1) v[k] = ok ? fmin(v[k], t) : v[k];
+            else if (k == special && op == 2) v[k] = ok ? fmax(v[k], t) : v[k];
+            else v[k] = ok ? v[k] + t : v[k];
+        }
+    }
     template <int CNT>
     __device__ __forceinline__ void seg_reduce(LaneT &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
-                                               bool contributes, int nsteps)
+                                               bool contributes, int nsteps, bool rows)
     {
-        for (int s = 0; s < nsteps; ++s) {
-            const bool ok = (L.segmask >> s) & 1;
-#pragma unroll
-            for (int k = 0; k < CNT; ++k) {
-                const double t = __shfl_down(v[k], 1 << s, 64);
-                if (k == special && op == 1) v[k] = ok ? fmin(v[k], t) : v[k];
-                else if (k == special && op == 2) v[k] = ok ? fmax(v[k], t) : v[k];
-                else v[k] = ok ? v[k] + t : v[k];
-            }
+        if (rows) {      // wave-uniform: segments never cross a 16-lane row, at most 4 steps
+            if (nsteps > 0) seg_step<CNT>(v, (L.segmask >> 0) & 1, special, op, [](double x) { return row_down<1>(x); });
+            if (nsteps > 1) seg_step<CNT>(v, (L.segmask >> 1) & 1, special, op, [](double x) { return row_down<2>(x); });
+            if (nsteps > 2) seg_step<CNT>(v, (L.segmask >> 2) & 1, special, op, [](double x) { return row_down<4>(x); });
+            if (nsteps > 3) seg_step<CNT>(v, (L.segmask >> 3) & 1, special, op, [](double x) { return row_down<8>(x); });
+        } else {
+            for (int s = 0; s < nsteps; ++s)
+                seg_step<CNT>(v, (L.segmask >> s) & 1, special, op, [s](double x) { return __shfl_down(x, 1 << s, 64); });
         }
         if (contributes && L.seg_head) {
             double *dst = L.out ? sout : sin;

@@ -25,7 +25,7 @@ template <int N> struct CpuExec {
     // lanes run in increasing order inside a phase: the head lane of a segment initialises the sum, the
     // following lanes of the segment accumulate (the GPU does the same reduction as a shuffle tree)
     template <int CNT> void seg_reduce(Lane<N> &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
-                                       bool contributes, int)
+                                       bool contributes, int, bool)
     {
         if (!contributes) return;
         double *dst = L.out ? sout : sin;
@@ -109,7 +109,7 @@ template <int N> struct CpuExec {
     // lanes run in increasing order inside a phase: the head lane of a segment initialises the sum, the
     // following lanes of the segment accumulate (the GPU does the same reduction as a shuffle tree)
     template <int CNT> void seg_reduce(Lane<N> &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
-                                       bool contributes, int)
+                                       bool contributes, int, bool)
     {
         if (!contributes) return;
         double *dst = L.out ? sout : sin;
