@@ -199,6 +199,7 @@ struct gcsadmm_handle_s {
     int n = 0, V = 0, E = 0, NI = 0, NI_owned = 0, c = 0, MM = 0, dtype = 0, device = 0;
     int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
     bool all_m4 = false;      // every generic vertex has exactly 4 facets -> the register-dual program
+    int align_rows = 0;       // group placement rule (group_base)
     double nx = 0, nmu = 0;
     gcsadmm_params params{};
     bool params_set = false;
@@ -272,7 +273,7 @@ static bool state_ok(gcsadmm_handle h, const gcsadmm_state *st)
 static VertexLaunchDesc make_launch_desc(gcsadmm_handle h, const gcsadmm_state *st)
 {
     VertexLaunchDesc d;
-    d.n_waves = h->n_waves; d.n_special = h->n_special; d.all_m4 = h->all_m4; d.lds_bytes = h->lds_bytes;
+    d.n_waves = h->n_waves; d.n_special = h->n_special; d.all_m4 = h->all_m4; d.lds_bytes = h->lds_bytes; d.align_rows = h->align_rows;
     d.wave_slot_ptr = h->d_wave_slot_ptr; d.wave_vtx = h->d_wave_vtx; d.special_vtx = h->d_special_vtx; d.special_kind = h->d_special_kind;
     d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
     d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
@@ -376,6 +377,9 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         // tuning knob: vertices per wavefront (still bounded by the LDS limit found above)
         if (const char *ov = getenv("GCSADMM_SLOTS")) slots_cap = std::max(1, std::min(lds_cap, atoi(ov)));
     }
+    // groups placed so that no side segment straddles a 16-lane row: the reductions then use DPP row shifts
+    // (vertex_program.inc group_base); costs lanes on graphs that would otherwise pack tighter
+    const int align_rows = getenv("GCSADMM_ALIGN") ? atoi(getenv("GCSADMM_ALIGN")) : 1;
     int lanes = 0, slots = 0, max_slots_used = 0;
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
@@ -386,12 +390,14 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
             continue;
         }
         if (d + 1 > WAVE) return fail(GCSADMM_ERR_UNSUPPORTED, "vertex degree above 63 is not supported by the vertex kernel");
-        if (lanes + d + 1 > WAVE || slots + 1 > slots_cap) {
+        int base = gcs::group_base(lanes, d, din, align_rows);
+        if (base < 0 || slots + 1 > slots_cap) {
             wave_slot_ptr.push_back((int)wave_vtx.size());
-            lanes = 0; slots = 0;
+            slots = 0;
+            base = gcs::group_base(0, d, din, align_rows);
         }
         wave_vtx.push_back(v);
-        lanes += d + 1; slots += 1;
+        lanes = base + d + 1; slots += 1;
         max_slots_used = std::max(max_slots_used, slots);
     }
     if ((int)wave_vtx.size() > wave_slot_ptr.back()) wave_slot_ptr.push_back((int)wave_vtx.size());
@@ -403,7 +409,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     h->dtype = g->state_dtype; h->device = g->device;
     h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
     h->slots_cap = std::max(1, max_slots_used);
-    h->all_m4 = all_m4;
+    h->all_m4 = all_m4; h->align_rows = align_rows;
     h->lds_bytes = (int)lds_need(h->slots_cap);
     h->nx = g->nx_global > 0 ? g->nx_global : (4.0 * n + 1) * (V + 2.0 * E);
     h->nmu = g->nmu_global > 0 ? g->nmu_global : (4.0 * n + 2) * E;

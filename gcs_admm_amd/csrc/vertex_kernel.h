@@ -14,7 +14,7 @@ constexpr int MAX_SPECIAL_DEG = 256;
 
 // everything a vertex-step launch needs, as plain pointers (device) and scalars
 struct VertexLaunchDesc {
-    int n_waves, n_special, all_m4, lds_bytes;
+    int n_waves, n_special, all_m4, lds_bytes, align_rows;
     const int *wave_slot_ptr, *wave_vtx, *special_vtx, *special_kind;
     const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
     const double *poly_A, *poly_bc, *center;
@@ -249,7 +249,7 @@ __global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb
 template <class PROG, int N, class T> static void launch_vertex_prog(const VertexLaunchDesc &d, hipStream_t s)
 {
     typename PROG::template Args<T> a;
-    a.n_waves = d.n_waves; a.wave_slot_ptr = d.wave_slot_ptr; a.wave_vtx = d.wave_vtx;
+    a.n_waves = d.n_waves; a.wave_slot_ptr = d.wave_slot_ptr; a.wave_vtx = d.wave_vtx; a.align_rows = d.align_rows;
     a.inc_ptr = d.inc_ptr; a.deg_in = d.deg_in; a.inc_edge = d.inc_edge; a.poly_ptr = d.poly_ptr;
     a.poly_A = d.poly_A; a.poly_bc = d.poly_bc; a.center = d.center;
     a.E = d.E; a.NI = d.NI; a.MM = d.MM;

@@ -59,19 +59,21 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
             bc[j] = s;
         }
     std::vector<int> wave_slot_ptr{0}, wave_vtx;
+    const int align_rows = getenv("GCS_EMU_ALIGN") ? atoi(getenv("GCS_EMU_ALIGN")) : 1;   // exercise the aligned placement by default
     int lanes = 0, slots = 0;
     for (int v = 0; v < V; ++v) {
         const int d = inc_ptr[v + 1] - inc_ptr[v], din = deg_in[v];
         is_generic[v] = !(v == src || v == dst || din == 0 || d - din == 0);
         if (!is_generic[v]) continue;
         if (d + 1 > WAVE) return 2;
-        if (lanes + d + 1 > WAVE || slots + 1 > MAX_SLOTS) { wave_slot_ptr.push_back((int)wave_vtx.size()); lanes = 0; slots = 0; }
-        wave_vtx.push_back(v); lanes += d + 1; slots += 1;
+        int b = group_base(lanes, d, din, align_rows);
+        if (b < 0 || slots + 1 > MAX_SLOTS) { wave_slot_ptr.push_back((int)wave_vtx.size()); slots = 0; b = group_base(0, d, din, align_rows); }
+        wave_vtx.push_back(v); lanes = b + d + 1; slots += 1;
     }
     if ((int)wave_vtx.size() > wave_slot_ptr.back()) wave_slot_ptr.push_back((int)wave_vtx.size());
     const int n_waves = (int)wave_slot_ptr.size() - 1;
     VertexArgs<double> a;
-    a.n_waves = n_waves; a.wave_slot_ptr = wave_slot_ptr.data(); a.wave_vtx = wave_vtx.data();
+    a.n_waves = n_waves; a.wave_slot_ptr = wave_slot_ptr.data(); a.wave_vtx = wave_vtx.data(); a.align_rows = align_rows;
     a.inc_ptr = inc_ptr; a.deg_in = deg_in.data(); a.inc_edge = inc_edge; a.poly_ptr = poly_ptr;
     a.poly_A = poly_A; a.poly_bc = bc.data(); a.center = center; a.E = E; a.NI = NI; a.MM = MM;
     a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
@@ -143,19 +145,21 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
             bc[j] = s;
         }
     std::vector<int> wave_slot_ptr{0}, wave_vtx;
+    const int align_rows = getenv("GCS_EMU_ALIGN") ? atoi(getenv("GCS_EMU_ALIGN")) : 1;   // exercise the aligned placement by default
     int lanes = 0, slots = 0;
     for (int v = 0; v < V; ++v) {
         const int d = inc_ptr[v + 1] - inc_ptr[v], din = deg_in[v];
         is_generic[v] = !(v == src || v == dst || din == 0 || d - din == 0);
         if (!is_generic[v]) continue;
         if (d + 1 > WAVE) return 2;
-        if (lanes + d + 1 > WAVE || slots + 1 > MAX_SLOTS) { wave_slot_ptr.push_back((int)wave_vtx.size()); lanes = 0; slots = 0; }
-        wave_vtx.push_back(v); lanes += d + 1; slots += 1;
+        int b = group_base(lanes, d, din, align_rows);
+        if (b < 0 || slots + 1 > MAX_SLOTS) { wave_slot_ptr.push_back((int)wave_vtx.size()); slots = 0; b = group_base(0, d, din, align_rows); }
+        wave_vtx.push_back(v); lanes = b + d + 1; slots += 1;
     }
     if ((int)wave_vtx.size() > wave_slot_ptr.back()) wave_slot_ptr.push_back((int)wave_vtx.size());
     const int n_waves = (int)wave_slot_ptr.size() - 1;
     VertexArgs<double> a;
-    a.n_waves = n_waves; a.wave_slot_ptr = wave_slot_ptr.data(); a.wave_vtx = wave_vtx.data();
+    a.n_waves = n_waves; a.wave_slot_ptr = wave_slot_ptr.data(); a.wave_vtx = wave_vtx.data(); a.align_rows = align_rows;
     a.inc_ptr = inc_ptr; a.deg_in = deg_in.data(); a.inc_edge = inc_edge; a.poly_ptr = poly_ptr;
     a.poly_A = poly_A; a.poly_bc = bc.data(); a.center = center; a.E = E; a.NI = NI; a.MM = MM;
     a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
