@@ -377,30 +377,46 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         // tuning knob: vertices per wavefront (still bounded by the LDS limit found above)
         if (const char *ov = getenv("GCSADMM_SLOTS")) slots_cap = std::max(1, std::min(lds_cap, atoi(ov)));
     }
-    // groups placed so that no side segment straddles a 16-lane row: the reductions then use DPP row shifts
-    // (vertex_program.inc group_base); costs lanes on graphs that would otherwise pack tighter
-    const int align_rows = getenv("GCSADMM_ALIGN") ? atoi(getenv("GCSADMM_ALIGN")) : 1;
-    int lanes = 0, slots = 0, max_slots_used = 0;
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
         if (v == g->src || v == g->dst || din == 0 || dout == 0) {
             if (d > MAX_SPECIAL_DEG) return fail(GCSADMM_ERR_UNSUPPORTED, "terminal vertex degree above 256");
             special_vtx.push_back(v);
             special_kind.push_back(v == g->src ? 1 : (v == g->dst ? 2 : 0));
-            continue;
+        } else if (d + 1 > WAVE) {
+            return fail(GCSADMM_ERR_UNSUPPORTED, "vertex degree above 63 is not supported by the vertex kernel");
         }
-        if (d + 1 > WAVE) return fail(GCSADMM_ERR_UNSUPPORTED, "vertex degree above 63 is not supported by the vertex kernel");
-        int base = gcs::group_base(lanes, d, din, align_rows);
-        if (base < 0 || slots + 1 > slots_cap) {
-            wave_slot_ptr.push_back((int)wave_vtx.size());
-            slots = 0;
-            base = gcs::group_base(0, d, din, align_rows);
-        }
-        wave_vtx.push_back(v);
-        lanes = base + d + 1; slots += 1;
-        max_slots_used = std::max(max_slots_used, slots);
     }
-    if ((int)wave_vtx.size() > wave_slot_ptr.back()) wave_slot_ptr.push_back((int)wave_vtx.size());
+    // Group placement (vertex_program.inc group_base).  Aligned: no side segment straddles a 16-lane row, the
+    // reductions use DPP row shifts (kernel RMODE 0).  Dense: groups back to back, more vertices per wavefront,
+    // reductions by chained wave shifts (RMODE 1, n = 2 only).  Aligned wins while the wavefronts fit the chip in
+    // two rounds (2 x 1024 one-wave-per-SIMD slots); beyond that throughput is per wavefront and dense wins
+    // (10k lattice: 1 490 vs 1 440 it/s; 100k lattice: 241 vs 264 it/s).
+    int max_slots_used = 0;
+    auto pack = [&](int align) {
+        wave_slot_ptr.assign(1, 0); wave_vtx.clear(); max_slots_used = 0;
+        int lanes = 0, slots = 0;
+        for (int v = 0; v < V; ++v) {
+            const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
+            if (v == g->src || v == g->dst || din == 0 || dout == 0) continue;
+            int base = gcs::group_base(lanes, d, din, align);
+            if (base < 0 || slots + 1 > slots_cap) {
+                wave_slot_ptr.push_back((int)wave_vtx.size());
+                slots = 0;
+                base = gcs::group_base(0, d, din, align);
+            }
+            wave_vtx.push_back(v);
+            lanes = base + d + 1; slots += 1;
+            max_slots_used = std::max(max_slots_used, slots);
+        }
+        if ((int)wave_vtx.size() > wave_slot_ptr.back()) wave_slot_ptr.push_back((int)wave_vtx.size());
+    };
+    int align_rows = 1;
+    pack(1);
+    if (const char *ov = getenv("GCSADMM_ALIGN")) align_rows = atoi(ov) != 0;        // tuning knob
+    else if (n == 2 && (int)wave_slot_ptr.size() - 1 > 2048) align_rows = 0;
+    if (n != 2) align_rows = 1;                                                       // RMODE 1 is built for n = 2 only
+    if (!align_rows) pack(0);
     const int n_waves = (int)wave_slot_ptr.size() - 1;
 
     auto *h = new (std::nothrow) gcsadmm_handle_s;

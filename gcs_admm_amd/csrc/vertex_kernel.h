@@ -31,7 +31,11 @@ struct VertexLaunchDesc {
 __device__ unsigned long long g_phase_cycles[64];
 #endif
 
-template <class LaneT> struct GpuExec {
+// RMODE: how the segmented reductions move data between lanes.  0 = DPP row shifts (host placed the groups so
+// that no side segment straddles a 16-lane row), 1 = chained DPP wave_shl:1 (dense packing, segments may cross
+// rows).  Either falls back to the ds_bpermute tree for a wavefront it cannot serve.  One mode per kernel
+// instantiation: carrying both paths in one kernel costs ~4 % (code size).
+template <class LaneT, int RMODE> struct GpuExec {
     LaneT &L;
     int lane;
 #ifdef GCS_PHASE_TIMING
@@ -72,6 +76,17 @@ template <class LaneT> struct GpuExec {
         hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + SH, 0xf, 0xf, true);
         return __hiloint2double(hi, lo);
     }
+    template <int SH> static __device__ __forceinline__ double wave_down(double x)
+    {
+        // lane i reads lane i + SH of the wavefront: SH chained DPP wave_shl:1 moves per half (lanes past 63 read 0)
+        int lo = __double2loint(x), hi = __double2hiint(x);
+#pragma unroll
+        for (int k = 0; k < SH; ++k) {
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+        }
+        return __hiloint2double(hi, lo);
+    }
     template <int CNT, class SHUF>
     static __device__ __forceinline__ void seg_step(double (&v)[CNT], bool ok, int special, int op, SHUF &&shuf)
     {
@@ -87,11 +102,15 @@ template <class LaneT> struct GpuExec {
     __device__ __forceinline__ void seg_reduce(LaneT &L, double (&v)[CNT], double *sin, double *sout, int special, int op,
                                                bool contributes, int nsteps, bool rows)
     {
-        if (rows) {      // wave-uniform: segments never cross a 16-lane row, at most 4 steps
+        if (RMODE == 0 && rows) {      // wave-uniform: segments never cross a 16-lane row, at most 4 steps
             if (nsteps > 0) seg_step<CNT>(v, (L.segmask >> 0) & 1, special, op, [](double x) { return row_down<1>(x); });
             if (nsteps > 1) seg_step<CNT>(v, (L.segmask >> 1) & 1, special, op, [](double x) { return row_down<2>(x); });
             if (nsteps > 2) seg_step<CNT>(v, (L.segmask >> 2) & 1, special, op, [](double x) { return row_down<4>(x); });
             if (nsteps > 3) seg_step<CNT>(v, (L.segmask >> 3) & 1, special, op, [](double x) { return row_down<8>(x); });
+        } else if (RMODE == 1 && nsteps <= 3) {   // segments cross rows: whole-wave shifts by one lane (DPP wave_shl:1), chained
+            if (nsteps > 0) seg_step<CNT>(v, (L.segmask >> 0) & 1, special, op, [](double x) { return wave_down<1>(x); });
+            if (nsteps > 1) seg_step<CNT>(v, (L.segmask >> 1) & 1, special, op, [](double x) { return wave_down<2>(x); });
+            if (nsteps > 2) seg_step<CNT>(v, (L.segmask >> 2) & 1, special, op, [](double x) { return wave_down<4>(x); });
         } else {
             for (int s = 0; s < nsteps; ++s)
                 seg_step<CNT>(v, (L.segmask >> s) & 1, special, op, [s](double x) { return __shfl_down(x, 1 << s, 64); });
@@ -133,7 +152,7 @@ struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet lo
     }
 };
 
-template <class PROG, int N, class T>
+template <class PROG, int N, class T, int RMODE>
 __global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Args<T> a, const gcsadmm_control_block *cb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -147,9 +166,9 @@ __global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Ar
     __shared__ unsigned long long acc[64];
     if (threadIdx.x < 64) acc[threadIdx.x] = 0;
     __syncthreads();
-    GpuExec<LaneT> ex{L, (int)threadIdx.x, 0, acc};
+    GpuExec<LaneT, RMODE> ex{L, (int)threadIdx.x, 0, acc};
 #else
-    GpuExec<LaneT> ex{L, (int)threadIdx.x};
+    GpuExec<LaneT, RMODE> ex{L, (int)threadIdx.x};
 #endif
     PROG::template run<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
 #ifdef GCS_PHASE_TIMING
@@ -256,7 +275,13 @@ template <class PROG, int N, class T> static void launch_vertex_prog(const Verte
     a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
     a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
     a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter;
-    hipLaunchKernelGGL((vertex_kernel<PROG, N, T>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb);
+    if constexpr (N == 2) {   // dense packing + wave shifts exists for the tuned dimension only
+        if (!d.align_rows) {
+            hipLaunchKernelGGL((vertex_kernel<PROG, N, T, 1>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((vertex_kernel<PROG, N, T, 0>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb);
 }
 
 // vertex step for space dimension N: generic vertices (wavefront program) + special vertices (closed form)
@@ -282,11 +307,15 @@ template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &
 
 template <int N, class T> static hipError_t set_lds_attr(bool all_m4, int lds_bytes)
 {
-    const void *fn = (const void *)vertex_kernel<ProgGeneric, N, T>;
+    hipError_t e = hipFuncSetAttribute((const void *)vertex_kernel<ProgGeneric, N, T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if constexpr (N == 2) {
-        if (all_m4) fn = (const void *)vertex_kernel<ProgM4, N, T>;
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)vertex_kernel<ProgGeneric, N, T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (all_m4) {
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)vertex_kernel<ProgM4, N, T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)vertex_kernel<ProgM4, N, T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        }
     }
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    return e;
 }
 
 } // namespace gcsadmm_k
