@@ -116,3 +116,21 @@ def test_emulated_wave_program_high_degree(emu, oracle_lib):
             mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
         assert np.abs(copy[:, mask] - o.copy[:, mask]).max() <= 2e-3
         o.edge_step(1.0)
+
+
+def test_group_placement_dense_equals_aligned(emu, monkeypatch):
+    """group_base(): the dense and the row-aligned placement of the vertex groups in a wavefront are two
+    schedules of the same computation -- identical results lane for lane (the emulation reduces in lane order)."""
+    from gcs_admm_amd.graph import lattice_boxes
+    g = lattice_boxes(9, 7, seed=4)
+    rng = np.random.default_rng(0)
+    zedge = 0.1 * rng.normal(size=(g.c, g.num_edges)); mu = 0.05 * rng.normal(size=(g.c, 2 * g.num_edges))
+    res = {}
+    for align in ("0", "1"):
+        monkeypatch.setenv("GCS_EMU_ALIGN", align)
+        res[align] = [emu_step(emu, g, zedge.copy(), mu.copy(), 1.3, 1.0, fn=f) for f in ("emu_vertex_step", "emu_vertex_step_m4")]
+    for k in range(2):
+        gen = res["0"][k][5] == 1
+        assert np.array_equal(res["0"][k][5], res["1"][k][5])
+        for a, b in zip(res["0"][k][:4], res["1"][k][:4]):
+            assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
