@@ -292,3 +292,25 @@ def test_degenerate_graphs(torch_gpu, oracle_lib):
     assert res["iterations"] == ora["iterations"] and res["status"] in ("converged", "max_it")
     assert np.isfinite(res["pri_res_seq"]).all() and np.isfinite(d.copy.cpu().numpy()).all()
     assert np.all(np.abs(res["pri_res_seq"] - ora["pri_res_seq"]) <= 2e-4 + 1e-3 * np.abs(ora["pri_res_seq"]))
+
+
+@pytest.mark.parametrize("knobs", [{"GCSADMM_ALIGN": "0", "GCSADMM_SLOTS": "7"}, {"GCSADMM_ALIGN": "1", "GCSADMM_SLOTS": "7"},
+                                   {"GCSADMM_ALIGN": "0", "GCSADMM_SLOTS": "7", "GCSADMM_NO_M4": "1"},
+                                   {"GCSADMM_ALIGN": "1", "GCSADMM_SLOTS": "3", "GCSADMM_NO_M4": "1"}])
+def test_packing_and_reduction_modes(torch_gpu, oracle_lib, monkeypatch, knobs):
+    """every schedule of the vertex kernel (dense packing + chained wave shifts, row-aligned packing + DPP row
+    shifts, generic and 4-facet program, 3 or 7 vertices per wavefront) gives the oracle's vertex step"""
+    torch = torch_gpu
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)                     # read by gcsadmm_create
+    g = lattice_boxes(14, 11, seed=7)
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    d = _solver(g)
+    d.reset()
+    for it in range(12):
+        d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu.copy_(torch.from_numpy(o.mu))
+        d.vertex_step()
+        assert o.vertex_step(1.0, 1.0) == 0
+        assert np.abs(d.copy.cpu().numpy() - o.copy).max() <= 1e-6
+        assert np.abs(d.yv.cpu().numpy() - o.yv).max() <= 1e-6
+        o.edge_step(1.0)
