@@ -353,7 +353,8 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
 
     // classify vertices and pack the generic ones into wavefronts: d+1 lanes each
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx;
-    bool all_m4 = (n == 2) && !getenv("GCSADMM_NO_M4");   // tuning knob: force the generic program
+    const char *no_m4 = getenv("GCSADMM_NO_M4");                  // tuning knob: 1 = force the generic program
+    bool all_m4 = (n == 2) && !(no_m4 && atoi(no_m4) != 0);
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
         const bool generic = !(v == g->src || v == g->dst || din == 0 || d - din == 0);
