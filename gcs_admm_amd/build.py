@@ -18,7 +18,7 @@ LP = os.path.join(CSRC, "polytope_lp.hip")      # batched tiny LPs for graph con
 UNITS.append((LP, "polytope_lp.o", []))
 HDR = os.path.join(ROOT, "include", "gcsadmm.h")
 DEPS = [MAIN, DIMS] + [os.path.join(CSRC, f) for f in ("vertex_program.h", "vertex_program.inc", "vertex_kernel.h")] + [HDR]
-UNIT_DEPS = {LP: [LP, HDR]}
+UNIT_DEPS = {LP: [LP, HDR, os.path.join(CSRC, "polytope_lp_core.h")]}
 OUT = os.path.join(HERE, "libgcsadmm.so")
 
 
@@ -31,7 +31,7 @@ def hipcc() -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Six objects compiled concurrently (the n = 6 instantiations take over a minute each), then linked."""
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + [LP]):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + UNIT_DEPS[LP]):
         return OUT
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if verbose:

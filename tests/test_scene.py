@@ -148,3 +148,59 @@ def test_device_lp_errors():
     A2 = np.vstack([np.eye(2), -np.eye(2)]); b2 = np.ones(4)
     with pytest.raises(GcsAdmmError, match="out of range"):
         PolytopeScene([(A2, b2)]).overlaps([0], [3])
+
+
+# ------------------------------------------------------------------------------------------- CPU: the LP core
+@pytest.fixture(scope="module")
+def lp_emu():
+    import ctypes as C
+    import subprocess
+    src = os.path.join(ROOT, "tests", "hostemu", "lp_emu.cpp")
+    out = os.path.join(ROOT, "tests", "hostemu", "liblpemu.so")
+    hdr = os.path.join(ROOT, "gcs_admm_amd", "csrc", "polytope_lp_core.h")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.dirname(hdr), src, "-o", out])
+    return C.CDLL(out)
+
+
+def _emu_ball(lib, polys, p, q, x0=None, early=0, tol=1e-9):
+    import ctypes as C
+    n = polys[0][0].shape[1]
+    ptr = np.zeros(len(polys) + 1, np.int32); ptr[1:] = np.cumsum([len(b) for _, b in polys])
+    A = np.ascontiguousarray(np.vstack([a for a, _ in polys])); b = np.ascontiguousarray(np.hstack([bb for _, bb in polys]))
+    nrm = np.ascontiguousarray(np.linalg.norm(A, axis=1))
+    w = np.zeros(n + 1); it = C.c_int(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    st = lib.lp_emu_ball(n, len(polys), vp(ptr), vp(A), vp(b), vp(nrm), p, q, vp(np.ascontiguousarray(x0)) if x0 is not None else None,
+                         early, C.c_double(tol), vp(w), C.byref(it))
+    return st, w, it.value
+
+
+@pytest.mark.parametrize("n", [2, 3, 6])
+def test_lp_core_against_oracle_on_the_host(lp_emu, n):
+    """the per-lane interior-point LP (host build of polytope_lp_core.h): Chebyshev radii and pairwise decisions
+    equal the oracle's HiGHS LPs, also for regions hundreds of units from the origin and for the reference's
+    1e-6 point boxes (utils.py:12-28), in a handful of Newton steps"""
+    from gcs_admm_amd.graph import convert_pt_to_polytope
+    rng = np.random.default_rng(n)
+    polys = [random_polytope(rng, n, 4 + n, rng.uniform(-1, 1, n) * s, rng.uniform(0.4, 1.2)) for s in (1, 1, 30, 30, 300, 300)]
+    polys += [random_polytope(rng, n, 3 + n, polys[k][1][-2 * n:-n] - 2 * 0.8 + rng.uniform(-0.5, 0.5, n), 0.8) for k in (0, 2, 4)]
+    polys += [convert_pt_to_polytope(rng.uniform(-1, 1, n) * 300)]
+    for p, (A, b) in enumerate(polys):
+        st, w, it = _emu_ball(lp_emu, polys, p, -1)
+        xo, ro = PO.chebyshev(A, b)
+        assert st == 0 and it <= 25, (p, st, it)
+        assert abs(w[n] - ro) <= 1e-9 * max(1.0, abs(ro)) + 1e-11, (p, w[n], ro)
+        assert ((b - A @ w[:n]) / np.linalg.norm(A, axis=1)).min() >= w[n] - 1e-9
+    cen = [PO.chebyshev(A, b)[0] for A, b in polys]
+    checked = 0
+    for p in range(len(polys)):
+        for q in range(p + 1, len(polys)):
+            r = PO.overlap_radius(polys[p][0], polys[p][1], polys[q][0], polys[q][1])
+            if abs(r) < 1e-7:
+                continue
+            st, w, it = _emu_ball(lp_emu, polys, p, q, x0=cen[p], early=1)
+            decided = (st == 1) or (st != 2 and w[n] >= -1e-9)
+            assert decided == (r > 0), (p, q, r, st, w[n])
+            checked += 1
+    assert checked >= 20
