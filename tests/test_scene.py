@@ -204,3 +204,30 @@ def test_lp_core_against_oracle_on_the_host(lp_emu, n):
             assert decided == (r > 0), (p, q, r, st, w[n])
             checked += 1
     assert checked >= 20
+
+
+@pytest.mark.gpu
+def test_device_scene_far_from_origin_end_to_end(oracle_lib):
+    """hexagons 300 units from the origin: device graph = oracle graph (every ordered pair by LP), all centre LPs
+    converge, and the ADMM loop on that graph follows the CPU oracle"""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from scale_demo import polygon_scene
+    from gcs_admm_amd.scene import PolytopeScene, graph_from_sets_device
+    from gcs_admm_amd.solver import DeviceSolver
+    As, bs = polygon_scene(8, seed=3)
+    shift = np.array([300.0, -250.0])
+    bs = {k: bs[k] + As[k] @ shift for k in As}
+    g = graph_from_sets_device(As, bs, 2)
+    assert [list(e) for e in PO.edges(As, bs)] == [[g.keys[t], g.keys[h]] for t, h in zip(g.edge_tail, g.edge_head)]
+    _, rad, st = PolytopeScene([(As[k], bs[k]) for k in As]).centers()
+    assert np.all(st == 0) and np.all(rad > 0)
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    d = DeviceSolver(g, "f64", device=0)
+    d.reset()
+    for it in range(10):
+        d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu.copy_(torch.from_numpy(o.mu))
+        d.vertex_step()
+        assert o.vertex_step(1.0, 1.0) == 0
+        assert np.abs(d.copy.cpu().numpy() - o.copy).max() <= 1e-5
+        o.edge_step(1.0)
