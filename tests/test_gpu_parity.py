@@ -314,3 +314,34 @@ def test_packing_and_reduction_modes(torch_gpu, oracle_lib, monkeypatch, knobs):
         assert np.abs(d.copy.cpu().numpy() - o.copy).max() <= 1e-6
         assert np.abs(d.yv.cpu().numpy() - o.yv).max() <= 1e-6
         o.edge_step(1.0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_fuzz(torch_gpu, oracle_lib, seed):
+    """random polygon scenes (3-7 facets, degrees 2-16), random penalty and dual scale: the vertex step of the
+    device equals the oracle's from random (not just reachable) states"""
+    torch = torch_gpu
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from scale_demo import polygon_scene
+    from gcs_admm_amd.graph import graph_from_sets
+    rng = np.random.default_rng(100 + seed)
+    As, bs = polygon_scene(5 + seed % 3, seed=seed, m=3 + seed % 5)
+    g = graph_from_sets(As, bs, 2)
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    d = _solver(g)
+    rho = float([0.25, 1.0, 4.0][seed % 3])
+    d.reset(rho=rho)
+    gen = _generic_mask(g)
+    for it in range(8):
+        if it >= 4:   # a random state around the current one
+            o.zedge += 0.05 * rng.normal(size=o.zedge.shape); o.mu += 0.02 * rng.normal(size=o.mu.shape)
+        d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu.copy_(torch.from_numpy(o.mu))
+        d.vertex_step()
+        assert o.vertex_step(rho, 1.0) == 0
+        diff = np.abs(d.copy.cpu().numpy() - o.copy)
+        # same bar as the step-by-step fixture tests: both solvers stop at mu <= 1e-9, weakly determined
+        # components (flat directions of a sub-problem) differ by up to ~1e-5, the bulk by far less
+        assert diff.max() <= 2e-3 and np.median(diff) <= 1e-7
+        assert np.abs(d.yv.cpu().numpy()[gen] - o.yv[gen]).max() <= 5e-4
+        o.edge_step(1.0)
