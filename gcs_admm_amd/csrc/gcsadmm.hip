@@ -200,6 +200,7 @@ struct gcsadmm_handle_s {
     int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
     bool all_m4 = false;      // every generic vertex has exactly 4 facets -> the register-dual program
     int align_rows = 0;       // group placement rule (group_base)
+    int store_dl = 0;         // LDS holds the final dual directions of the facet rows (kernel template SDL)
     double nx = 0, nmu = 0;
     gcsadmm_params params{};
     bool params_set = false;
@@ -273,7 +274,7 @@ static bool state_ok(gcsadmm_handle h, const gcsadmm_state *st)
 static VertexLaunchDesc make_launch_desc(gcsadmm_handle h, const gcsadmm_state *st)
 {
     VertexLaunchDesc d;
-    d.n_waves = h->n_waves; d.n_special = h->n_special; d.all_m4 = h->all_m4; d.lds_bytes = h->lds_bytes; d.align_rows = h->align_rows;
+    d.n_waves = h->n_waves; d.n_special = h->n_special; d.all_m4 = h->all_m4; d.lds_bytes = h->lds_bytes; d.align_rows = h->align_rows; d.store_dl = h->store_dl;
     d.wave_slot_ptr = h->d_wave_slot_ptr; d.wave_vtx = h->d_wave_vtx; d.special_vtx = h->d_special_vtx; d.special_kind = h->d_special_kind;
     d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
     d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
@@ -360,7 +361,11 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         const bool generic = !(v == g->src || v == g->dst || din == 0 || d - din == 0);
         if (generic && g->poly_ptr[v + 1] - g->poly_ptr[v] != 4) all_m4 = false;
     }
-    auto lds_need = [&](int slots) { return (size_t)(all_m4 ? gcs_m4::lds_doubles(n, MM, slots) : gcs::lds_doubles(n, MM, slots)) * 8; };
+    // LDS per wavefront with / without room for the final dual directions (kernel template SDL): they save the
+    // update pass its facet rows (10k lattice +5 %) but must not cost a resident wavefront: kept only while four
+    // wavefronts still fit a CU's 160 KB (n = 2 only)
+    int store_dl = 0;
+    auto lds_need = [&](int slots) { return (size_t)(all_m4 ? gcs_m4::lds_doubles(n, MM, slots, store_dl) : gcs::lds_doubles(n, MM, slots, store_dl)) * 8; };
     int slots_cap = MAX_SLOTS;
     while (slots_cap > 1 && lds_need(slots_cap) > 160 * 1024) --slots_cap;
     if (lds_need(slots_cap) > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
@@ -427,6 +432,13 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
     h->slots_cap = std::max(1, max_slots_used);
     h->all_m4 = all_m4; h->align_rows = align_rows;
+    if (n == 2) {
+        store_dl = 1;
+        if (lds_need(h->slots_cap) > 40 * 1024) store_dl = 0;
+        if (const char *ov = getenv("GCSADMM_STORE_DL")) store_dl = atoi(ov) != 0;   // tuning knob
+        if (store_dl && lds_need(h->slots_cap) > 160 * 1024) store_dl = 0;
+    }
+    h->store_dl = store_dl;
     h->lds_bytes = (int)lds_need(h->slots_cap);
     h->nx = g->nx_global > 0 ? g->nx_global : (4.0 * n + 1) * (V + 2.0 * E);
     h->nmu = g->nmu_global > 0 ? g->nmu_global : (4.0 * n + 2) * E;

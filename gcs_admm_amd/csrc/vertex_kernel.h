@@ -14,7 +14,7 @@ constexpr int MAX_SPECIAL_DEG = 256;
 
 // everything a vertex-step launch needs, as plain pointers (device) and scalars
 struct VertexLaunchDesc {
-    int n_waves, n_special, all_m4, lds_bytes, align_rows;
+    int n_waves, n_special, all_m4, lds_bytes, align_rows, store_dl;
     const int *wave_slot_ptr, *wave_vtx, *special_vtx, *special_kind;
     const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
     const double *poly_A, *poly_bc, *center;
@@ -133,33 +133,35 @@ struct ProgGeneric {   // any facet count per polytope, facet-row duals in LDS
     template <int N> using LaneT = gcs::Lane<N>;
     template <class T> using Args = gcs::VertexArgs<T>;
     using Shared = gcs::WaveShared;
-    static __device__ __forceinline__ void shared_init(Shared &S, double *smem, int n, int mm) { gcs::wave_shared_init(S, smem, n, mm); }
-    template <int N, class T, class EX>
+    static __device__ __forceinline__ void shared_init(Shared &S, double *smem, int n, int mm, int dl) { gcs::wave_shared_init(S, smem, n, mm, dl); }
+    template <int N, class T, int SDL, class EX>
     static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
     {
-        gcs::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
+        gcs::run_vertex_program<N, T, SDL>(ex, w, a, S, rho, ms);
     }
 };
 struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet loops, row duals in registers
     template <int N> using LaneT = gcs_m4::Lane<N>;
     template <class T> using Args = gcs_m4::VertexArgs<T>;
     using Shared = gcs_m4::WaveShared;
-    static __device__ __forceinline__ void shared_init(Shared &S, double *smem, int n, int mm) { gcs_m4::wave_shared_init(S, smem, n, mm); }
-    template <int N, class T, class EX>
+    static __device__ __forceinline__ void shared_init(Shared &S, double *smem, int n, int mm, int dl) { gcs_m4::wave_shared_init(S, smem, n, mm, dl); }
+    template <int N, class T, int SDL, class EX>
     static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
     {
-        gcs_m4::run_vertex_program<N, T>(ex, w, a, S, rho, ms);
+        gcs_m4::run_vertex_program<N, T, SDL>(ex, w, a, S, rho, ms);
     }
 };
 
-template <class PROG, int N, class T, int RMODE>
+// SDL = 1: the LDS allocation has room for the final dual directions of the facet rows (lds_doubles(.., 1)); the
+// update pass applies them instead of recomputing the rows.  Chosen by the host when it does not cost occupancy.
+template <class PROG, int N, class T, int RMODE, int SDL>
 __global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Args<T> a, const gcsadmm_control_block *cb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (cb->status != GCSADMM_RUNNING) return;
     const double rho = cb->rho, mu_scale = cb->mu_scale;
     typename PROG::Shared S;
-    PROG::shared_init(S, smem, N, a.MM);
+    PROG::shared_init(S, smem, N, a.MM, SDL);
     using LaneT = typename PROG::template LaneT<N>;
     LaneT L;
 #ifdef GCS_PHASE_TIMING
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Ar
 #else
     GpuExec<LaneT, RMODE> ex{L, (int)threadIdx.x};
 #endif
-    PROG::template run<N, T>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
+    PROG::template run<N, T, SDL>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
 #ifdef GCS_PHASE_TIMING
     __syncthreads();
     if (threadIdx.x < 64) atomicAdd(&g_phase_cycles[threadIdx.x], acc[threadIdx.x]);
@@ -275,13 +277,14 @@ template <class PROG, int N, class T> static void launch_vertex_prog(const Verte
     a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
     a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
     a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter;
-    if constexpr (N == 2) {   // dense packing + wave shifts exists for the tuned dimension only
-        if (!d.align_rows) {
-            hipLaunchKernelGGL((vertex_kernel<PROG, N, T, 1>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb);
-            return;
-        }
+#define GCS_LAUNCH(RM, DL) hipLaunchKernelGGL((vertex_kernel<PROG, N, T, RM, DL>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb)
+    if constexpr (N == 2) {   // dense packing + wave shifts, and the stored dual directions, exist for the tuned dimension only
+        if (!d.align_rows) { if (d.store_dl) GCS_LAUNCH(1, 1); else GCS_LAUNCH(1, 0); }
+        else { if (d.store_dl) GCS_LAUNCH(0, 1); else GCS_LAUNCH(0, 0); }
+    } else {
+        GCS_LAUNCH(0, 0);
     }
-    hipLaunchKernelGGL((vertex_kernel<PROG, N, T, 0>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb);
+#undef GCS_LAUNCH
 }
 
 // vertex step for space dimension N: generic vertices (wavefront program) + special vertices (closed form)
@@ -307,12 +310,18 @@ template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &
 
 template <int N, class T> static hipError_t set_lds_attr(bool all_m4, int lds_bytes)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)vertex_kernel<ProgGeneric, N, T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipError_t e = hipSuccess;
+    auto set = [&](const void *fn) { if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); };
+    set((const void *)vertex_kernel<ProgGeneric, N, T, 0, 0>);
     if constexpr (N == 2) {
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)vertex_kernel<ProgGeneric, N, T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        set((const void *)vertex_kernel<ProgGeneric, N, T, 0, 1>);
+        set((const void *)vertex_kernel<ProgGeneric, N, T, 1, 0>);
+        set((const void *)vertex_kernel<ProgGeneric, N, T, 1, 1>);
         if (all_m4) {
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)vertex_kernel<ProgM4, N, T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)vertex_kernel<ProgM4, N, T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            set((const void *)vertex_kernel<ProgM4, N, T, 0, 0>);
+            set((const void *)vertex_kernel<ProgM4, N, T, 0, 1>);
+            set((const void *)vertex_kernel<ProgM4, N, T, 1, 0>);
+            set((const void *)vertex_kernel<ProgM4, N, T, 1, 1>);
         }
     }
     return e;

@@ -60,6 +60,7 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
         }
     std::vector<int> wave_slot_ptr{0}, wave_vtx;
     const int align_rows = getenv("GCS_EMU_ALIGN") ? atoi(getenv("GCS_EMU_ALIGN")) : 1;   // exercise the aligned placement by default
+    const int STORE_DL = getenv("GCS_EMU_STORE_DL") ? atoi(getenv("GCS_EMU_STORE_DL")) : 1;   // and the stored dual directions
     int lanes = 0, slots = 0;
     for (int v = 0; v < V; ++v) {
         const int d = inc_ptr[v + 1] - inc_ptr[v], din = deg_in[v];
@@ -78,14 +79,15 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
     a.poly_A = poly_A; a.poly_bc = bc.data(); a.center = center; a.E = E; a.NI = NI; a.MM = MM;
     a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
     a.eps_edge = eps_edge; a.ipm_tol = ipm_tol; a.ipm_max_iter = ipm_max_iter;
-    std::vector<double> smem(lds_doubles(n, MM, MAX_SLOTS));
+    std::vector<double> smem(lds_doubles(n, MM, MAX_SLOTS, STORE_DL));
     auto run_all = [&](auto *ex, auto ntag) {
         constexpr int NN = decltype(ntag)::value;
         for (int w = 0; w < n_waves; ++w) {
             std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
             WaveShared S;
-            wave_shared_init(S, smem.data(), n, MM);
-            run_vertex_program<NN, double>(*ex, w, a, S, rho, mu_scale);
+            wave_shared_init(S, smem.data(), n, MM, STORE_DL);
+            if (STORE_DL) run_vertex_program<NN, double, 1>(*ex, w, a, S, rho, mu_scale);
+            else run_vertex_program<NN, double, 0>(*ex, w, a, S, rho, mu_scale);
         }
         delete ex;
     };
@@ -146,6 +148,7 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
         }
     std::vector<int> wave_slot_ptr{0}, wave_vtx;
     const int align_rows = getenv("GCS_EMU_ALIGN") ? atoi(getenv("GCS_EMU_ALIGN")) : 1;   // exercise the aligned placement by default
+    const int STORE_DL = getenv("GCS_EMU_STORE_DL") ? atoi(getenv("GCS_EMU_STORE_DL")) : 1;   // and the stored dual directions
     int lanes = 0, slots = 0;
     for (int v = 0; v < V; ++v) {
         const int d = inc_ptr[v + 1] - inc_ptr[v], din = deg_in[v];
@@ -164,14 +167,15 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
     a.poly_A = poly_A; a.poly_bc = bc.data(); a.center = center; a.E = E; a.NI = NI; a.MM = MM;
     a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
     a.eps_edge = eps_edge; a.ipm_tol = ipm_tol; a.ipm_max_iter = ipm_max_iter;
-    std::vector<double> smem(lds_doubles(n, MM, MAX_SLOTS));
+    std::vector<double> smem(lds_doubles(n, MM, MAX_SLOTS, STORE_DL));
     auto run_all = [&](auto *ex, auto ntag) {
         constexpr int NN = decltype(ntag)::value;
         for (int w = 0; w < n_waves; ++w) {
             std::fill(smem.begin(), smem.end(), 0.0 / 0.0);   // poison: reads of unwritten LDS show up as NaN
             WaveShared S;
-            wave_shared_init(S, smem.data(), n, MM);
-            run_vertex_program<NN, double>(*ex, w, a, S, rho, mu_scale);
+            wave_shared_init(S, smem.data(), n, MM, STORE_DL);
+            if (STORE_DL) run_vertex_program<NN, double, 1>(*ex, w, a, S, rho, mu_scale);
+            else run_vertex_program<NN, double, 0>(*ex, w, a, S, rho, mu_scale);
         }
         delete ex;
     };

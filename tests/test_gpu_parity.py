@@ -296,10 +296,12 @@ def test_degenerate_graphs(torch_gpu, oracle_lib):
 
 @pytest.mark.parametrize("knobs", [{"GCSADMM_ALIGN": "0", "GCSADMM_SLOTS": "7"}, {"GCSADMM_ALIGN": "1", "GCSADMM_SLOTS": "7"},
                                    {"GCSADMM_ALIGN": "0", "GCSADMM_SLOTS": "7", "GCSADMM_NO_M4": "1"},
-                                   {"GCSADMM_ALIGN": "1", "GCSADMM_SLOTS": "3", "GCSADMM_NO_M4": "1"}])
+                                   {"GCSADMM_ALIGN": "1", "GCSADMM_SLOTS": "3", "GCSADMM_NO_M4": "1"},
+                                   {"GCSADMM_ALIGN": "1", "GCSADMM_STORE_DL": "0"}, {"GCSADMM_ALIGN": "0", "GCSADMM_STORE_DL": "0", "GCSADMM_NO_M4": "1"}])
 def test_packing_and_reduction_modes(torch_gpu, oracle_lib, monkeypatch, knobs):
     """every schedule of the vertex kernel (dense packing + chained wave shifts, row-aligned packing + DPP row
-    shifts, generic and 4-facet program, 3 or 7 vertices per wavefront) gives the oracle's vertex step"""
+    shifts, generic and 4-facet program, 3 or 7 vertices per wavefront, update pass from stored directions or
+    recomputed rows) gives the oracle's vertex step"""
     torch = torch_gpu
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)                     # read by gcsadmm_create
