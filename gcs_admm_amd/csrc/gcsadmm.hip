@@ -5,8 +5,9 @@
 //                        wavefront, program in vertex_program.h          (admm_solver_v3.py:352-540)
 //   special_kernel<N,T>  x-update of s, t (closed form) and of vertices no flow can cross
 //   edge_kernel<T>       z-update, dual update, five partial norms        (admm_solver_v3.py:543-614)
-//   control_kernel       deterministic final reduction, residuals, rho adaptation, stop test,
-//                        trace record                                      (admm_solver_v3.py:697-733)
+//   finalize_kernel / control_kernel   deterministic final reduction; residuals, rho adaptation, stop test,
+//                        trace record (admm_solver_v3.py:697-733); gcsadmm_run uses the fused variants
+//                        (edge_kernel<T, true>, finalize_control_kernel): fewer launches per iteration
 //   cost_kernel<T>       GCS_utils.py:184-211
 #include <hip/hip_runtime.h>
 
@@ -63,8 +64,55 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-template <class T>
-__global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, const gcsadmm_control_block *cb)
+struct ControlParams {
+    double tau_incr, tau_decr, nu, eps_abs, eps_rel, nx, nmu;
+    int it_rho_limit, max_it;
+};
+
+// admm_solver_v3.py:697-733 on the five (globally reduced) sums; one thread
+__device__ void control_body(gcsadmm_control_block *cb, const double *sums, const ControlParams &p, int *counters, double *trace)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    double s[5];
+    for (int k = 0; k < 5; ++k) { s[k] = sums[k]; cb->sums[k] = s[k]; }
+    const int it = cb->it;
+    double rho = cb->rho;
+    const int fails = counters[0], iters = counters[1];
+    counters[0] = 0; counters[1] = 0;
+    cb->inner_failures = fails; cb->inner_iters = iters;
+    const double tot = s[0] + s[1] + s[2] + s[3] + s[4];
+    if (!(tot == tot) || fabs(tot) > 1.7e308) {   // non-finite iterate: admm_solver_v3.py:662-664, 679-681
+        cb->status = GCSADMM_DIVERGED;
+        return;
+    }
+    const double pri = sqrt(s[0]), dual = rho * sqrt(2.0 * s[1]);
+    double mu_scale = 1.0;
+    if (pri >= p.nu * dual && it < p.it_rho_limit) { rho *= p.tau_incr; mu_scale = 1.0 / p.tau_incr; }
+    else if (dual >= p.nu * pri && it < p.it_rho_limit) { rho *= 1.0 / p.tau_decr; mu_scale = p.tau_incr; }
+    const double eps_pri = sqrt(p.nx) * p.eps_abs + p.eps_rel * fmax(sqrt(s[2]), sqrt(2.0 * s[3]));
+    const double eps_dual = sqrt(p.nmu) * p.eps_abs + p.eps_rel * mu_scale * sqrt(s[4]);
+    cb->rho = rho; cb->mu_scale = mu_scale;
+    cb->pri = pri; cb->dual = dual; cb->eps_pri = eps_pri; cb->eps_dual = eps_dual;
+    if (trace) {
+        double *tr = trace + (size_t)(it - 1) * 6;
+        tr[0] = rho; tr[1] = pri; tr[2] = dual; tr[3] = eps_pri; tr[4] = eps_dual; tr[5] = (double)fails;
+    }
+    if (pri < eps_pri && dual < eps_dual) { cb->status = GCSADMM_CONVERGED; return; }
+    cb->it = it + 1;
+    if (it + 1 > p.max_it) cb->status = GCSADMM_MAX_IT;
+}
+
+__global__ void control_kernel(gcsadmm_control_block *cb, const double *sums, ControlParams p, int *counters, double *trace)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    control_body(cb, sums, p, counters, trace);
+}
+
+// FUSED (single workgroup, i.e. at most EDGE_BLOCK edges: gcsadmm_run on small graphs): the workgroup also does the
+// final reduction and the control step, which saves two ~4 us launches per iteration
+template <class T, bool FUSED>
+__global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm_control_block *cb, double *sums, ControlParams cp,
+                                                          int *counters, double *trace)
 {
     if (cb->status != GCSADMM_RUNNING) return;
     const double mu_scale = cb->mu_scale;
@@ -105,6 +153,11 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, const g
         double t = 0;
         for (int q = 0; q < EDGE_BLOCK / WAVE; ++q) t += red[q][threadIdx.x];
         a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
+        if (FUSED) sums[threadIdx.x] = t;      // one workgroup: its partial is the sum (what finalize_kernel would produce)
+    }
+    if (FUSED) {
+        __syncthreads();
+        if (threadIdx.x == 0) control_body(cb, sums, cp, counters, trace);
     }
 }
 
@@ -127,43 +180,25 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *partials, i
     if (threadIdx.x < 5) sums[threadIdx.x] = red[0][threadIdx.x];
 }
 
-struct ControlParams {
-    double tau_incr, tau_decr, nu, eps_abs, eps_rel, nx, nmu;
-    int it_rho_limit, max_it;
-};
-
-// admm_solver_v3.py:697-733 on the five (globally reduced) sums
-__global__ void control_kernel(gcsadmm_control_block *cb, const double *sums, ControlParams p, int *counters, double *trace)
+// the same reduction followed by the control step (gcsadmm_run: one launch instead of two)
+__global__ __launch_bounds__(256) void finalize_control_kernel(const double *partials, int nblocks, double *sums, gcsadmm_control_block *cb,
+                                                              ControlParams cp, int *counters, double *trace)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (cb->status != GCSADMM_RUNNING) return;
-    double s[5];
-    for (int k = 0; k < 5; ++k) { s[k] = sums[k]; cb->sums[k] = s[k]; }
-    const int it = cb->it;
-    double rho = cb->rho;
-    const int fails = counters[0], iters = counters[1];
-    counters[0] = 0; counters[1] = 0;
-    cb->inner_failures = fails; cb->inner_iters = iters;
-    const double tot = s[0] + s[1] + s[2] + s[3] + s[4];
-    if (!(tot == tot) || fabs(tot) > 1.7e308) {   // non-finite iterate: admm_solver_v3.py:662-664, 679-681
-        cb->status = GCSADMM_DIVERGED;
-        return;
+    __shared__ double red[256][5];
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int k = 0; k < 5; ++k) s[k] += partials[(size_t)b * 5 + k];
+    for (int k = 0; k < 5; ++k) red[threadIdx.x][k] = s[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 5; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+        __syncthreads();
     }
-    const double pri = sqrt(s[0]), dual = rho * sqrt(2.0 * s[1]);
-    double mu_scale = 1.0;
-    if (pri >= p.nu * dual && it < p.it_rho_limit) { rho *= p.tau_incr; mu_scale = 1.0 / p.tau_incr; }
-    else if (dual >= p.nu * pri && it < p.it_rho_limit) { rho *= 1.0 / p.tau_decr; mu_scale = p.tau_incr; }
-    const double eps_pri = sqrt(p.nx) * p.eps_abs + p.eps_rel * fmax(sqrt(s[2]), sqrt(2.0 * s[3]));
-    const double eps_dual = sqrt(p.nmu) * p.eps_abs + p.eps_rel * mu_scale * sqrt(s[4]);
-    cb->rho = rho; cb->mu_scale = mu_scale;
-    cb->pri = pri; cb->dual = dual; cb->eps_pri = eps_pri; cb->eps_dual = eps_dual;
-    if (trace) {
-        double *tr = trace + (size_t)(it - 1) * 6;
-        tr[0] = rho; tr[1] = pri; tr[2] = dual; tr[3] = eps_pri; tr[4] = eps_dual; tr[5] = (double)fails;
-    }
-    if (pri < eps_pri && dual < eps_dual) { cb->status = GCSADMM_CONVERGED; return; }
-    cb->it = it + 1;
-    if (it + 1 > p.max_it) cb->status = GCSADMM_MAX_IT;
+    if (threadIdx.x < 5) sums[threadIdx.x] = red[0][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) control_body(cb, sums, cp, counters, trace);
 }
 
 template <class T>
@@ -252,14 +287,23 @@ template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const g
     return GCSADMM_OK;
 }
 
-template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcsadmm_state *st, double *sums, hipStream_t s)
+// with_control: the control step rides in the same launches (gcsadmm_run); trace may be null
+template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcsadmm_state *st, double *sums, hipStream_t s,
+                                                     bool with_control = false, double *trace = nullptr)
 {
+    const gcsadmm_params &pp = h->params;
+    const ControlParams cp{pp.tau_incr, pp.tau_decr, pp.nu, pp.eps_abs, pp.eps_rel, h->nx, h->nmu, pp.it_rho_limit, pp.max_it};
     EdgeArgs<T> a;
     a.E = h->E; a.NI = h->NI; a.c = h->c; a.edge_inc_tail = h->d_edge_inc_tail; a.edge_inc_head = h->d_edge_inc_head;
     a.inc_counted = h->d_inc_counted; a.edge_counted = h->d_edge_counted;
     a.copy = (const T *)st->copy; a.zedge = (T *)st->zedge; a.mu = (T *)st->mu; a.partials = h->d_partials;
-    hipLaunchKernelGGL((edge_kernel<T>), dim3(h->edge_blocks), dim3(EDGE_BLOCK), 0, s, a, h->d_cb);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, h->d_partials, h->edge_blocks, sums, h->d_cb);
+    if (with_control && h->edge_blocks == 1) {
+        hipLaunchKernelGGL((edge_kernel<T, true>), dim3(1), dim3(EDGE_BLOCK), 0, s, a, h->d_cb, sums, cp, h->d_counters, trace);
+    } else {
+        hipLaunchKernelGGL((edge_kernel<T, false>), dim3(h->edge_blocks), dim3(EDGE_BLOCK), 0, s, a, h->d_cb, sums, cp, h->d_counters, trace);
+        if (with_control) hipLaunchKernelGGL(finalize_control_kernel, dim3(1), dim3(256), 0, s, h->d_partials, h->edge_blocks, sums, h->d_cb, cp, h->d_counters, trace);
+        else hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, h->d_partials, h->edge_blocks, sums, h->d_cb);
+    }
     HIPCHK(h, hipGetLastError());
     return GCSADMM_OK;
 }
@@ -525,8 +569,10 @@ gcsadmm_status gcsadmm_run(gcsadmm_handle h, const gcsadmm_state *st, int32_t k,
     for (int i = 0; i < k; ++i) {
         gcsadmm_status s;
         if ((s = gcsadmm_vertex_step(h, st, stream)) != GCSADMM_OK) return s;
-        if ((s = gcsadmm_edge_step(h, st, h->d_sums, stream)) != GCSADMM_OK) return s;
-        if ((s = gcsadmm_control(h, h->d_sums, trace_dev, stream)) != GCSADMM_OK) return s;
+        // edge step and control step in two launches (one when all edges fit a single workgroup)
+        s = h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, h->d_sums, (hipStream_t)stream, true, trace_dev)
+                                    : launch_edge<float>(h, st, h->d_sums, (hipStream_t)stream, true, trace_dev);
+        if (s != GCSADMM_OK) return s;
     }
     return GCSADMM_OK;
 }
@@ -549,9 +595,9 @@ gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int3
         if ((r = gcsadmm_vertex_step(h, st, stream)) != GCSADMM_OK) return r;
         HIPCHK(h, hipEventRecord(h->events[4 * i + 1], s));
         HIPCHK(h, hipEventRecord(h->events[4 * i + 2], s));
-        if ((r = gcsadmm_edge_step(h, st, h->d_sums, stream)) != GCSADMM_OK) return r;
+        r = h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, h->d_sums, s, true, trace_dev) : launch_edge<float>(h, st, h->d_sums, s, true, trace_dev);
+        if (r != GCSADMM_OK) return r;
         HIPCHK(h, hipEventRecord(h->events[4 * i + 3], s));
-        if ((r = gcsadmm_control(h, h->d_sums, trace_dev, stream)) != GCSADMM_OK) return r;
     }
     HIPCHK(h, hipStreamSynchronize(s));
     double vm = 0, em = 0;
