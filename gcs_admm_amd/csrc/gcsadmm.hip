@@ -3,7 +3,8 @@
 // Kernels (one HIP stream, launched back to back, no host round trip inside the loop):
 //   vertex_kernel<N,T>   x-update, generic vertices: one wavefront per workgroup, several vertices per
 //                        wavefront, program in vertex_program.h          (admm_solver_v3.py:352-540)
-//   special_kernel<N,T>  x-update of s, t (closed form) and of vertices no flow can cross
+//                        trailing workgroups of the same launch: x-update of s, t (closed form) and of vertices
+//                        no flow can cross (special_body)
 //   edge_kernel<T>       z-update, dual update, five partial norms        (admm_solver_v3.py:543-614)
 //   finalize_kernel / control_kernel   deterministic final reduction; residuals, rho adaptation, stop test,
 //                        trace record (admm_solver_v3.py:697-733); gcsadmm_run uses the fused variants

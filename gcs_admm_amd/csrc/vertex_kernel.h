@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "gcsadmm.h"
 #include "vertex_program.h"
 
@@ -152,33 +154,6 @@ struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet lo
     }
 };
 
-// SDL = 1: the LDS allocation has room for the final dual directions of the facet rows (lds_doubles(.., 1)); the
-// update pass applies them instead of recomputing the rows.  Chosen by the host when it does not cost occupancy.
-template <class PROG, int N, class T, int RMODE, int SDL>
-__global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Args<T> a, const gcsadmm_control_block *cb)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (cb->status != GCSADMM_RUNNING) return;
-    const double rho = cb->rho, mu_scale = cb->mu_scale;
-    typename PROG::Shared S;
-    PROG::shared_init(S, smem, N, a.MM, SDL);
-    using LaneT = typename PROG::template LaneT<N>;
-    LaneT L;
-#ifdef GCS_PHASE_TIMING
-    __shared__ unsigned long long acc[64];
-    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
-    __syncthreads();
-    GpuExec<LaneT, RMODE> ex{L, (int)threadIdx.x, 0, acc};
-#else
-    GpuExec<LaneT, RMODE> ex{L, (int)threadIdx.x};
-#endif
-    PROG::template run<N, T, SDL>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
-#ifdef GCS_PHASE_TIMING
-    __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(&g_phase_cycles[threadIdx.x], acc[threadIdx.x]);
-#endif
-}
-
 // -------------------------------------------------------------------------------------------------
 // special vertices: s / t are points (utils.py:12-28, boxes of half-width 1e-6) -> the sub-problem
 // collapses to a separable quadratic over the simplex of the live side; a vertex with no incoming or
@@ -197,13 +172,10 @@ template <class T> struct SpecialArgs {
     double eps_edge;
 };
 
+// vals / u: work arrays of MAX_SPECIAL_DEG doubles each, used by the source and the target only
 template <int N, class T>
-__global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb)
+__device__ void special_body(const SpecialArgs<T> &a, int i, double rho, double mu_scale, double *vals, double *u)
 {
-    if (cb->status != GCSADMM_RUNNING) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.count) return;
-    const double rho = cb->rho, mu_scale = cb->mu_scale;
     const int v = a.vtx[i], kind = a.kind[i];
     const int lo = a.inc_ptr[v], d = a.inc_ptr[v + 1] - lo, d_in = a.deg_in[v];
     double cen[N];
@@ -216,7 +188,6 @@ __global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb
     const bool is_src = kind == 1, is_dst = kind == 2;
     const int live_lo = is_src ? d_in : 0, live_hi = is_src ? d : (is_dst ? d_in : 0);
     const int na = live_hi - live_lo;
-    double vals[MAX_SPECIAL_DEG];
     double tau = 0.0;
     if (na > 0) {
         double pp = 0;
@@ -230,7 +201,6 @@ __global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb
             vals[e - live_lo] = (cc - a.eps_edge / rho) / aq;
         }
         // threshold of the Euclidean projection onto the simplex: sort descending (insertion), scan
-        double u[MAX_SPECIAL_DEG];
         for (int q = 0; q < na; ++q) u[q] = vals[q];
         for (int q = 1; q < na; ++q) {
             const double x = u[q];
@@ -267,6 +237,41 @@ __global__ void special_kernel(SpecialArgs<T> a, const gcsadmm_control_block *cb
 }
 
 
+// SDL = 1: the LDS allocation has room for the final dual directions of the facet rows (lds_doubles(.., 1)); the
+// update pass applies them instead of recomputing the rows.  Chosen by the host when it does not cost occupancy.
+template <class PROG, int N, class T, int RMODE, int SDL>
+__global__ __launch_bounds__(WAVE) void vertex_kernel(typename PROG::template Args<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (cb->status != GCSADMM_RUNNING) return;
+    const double rho = cb->rho, mu_scale = cb->mu_scale;
+    if ((int)blockIdx.x >= a.n_waves) {   // trailing workgroups: the special vertices, one per lane (saves a ~4 us launch per iteration)
+        const int i = ((int)blockIdx.x - a.n_waves) * WAVE + (int)threadIdx.x;
+        if (i < sp.count) {
+            double *vals = smem + (sp.kind[i] == 2 ? 2 * MAX_SPECIAL_DEG : 0);   // source and target: own work arrays in LDS
+            special_body<N, T>(sp, i, rho, mu_scale, vals, vals + MAX_SPECIAL_DEG);
+        }
+        return;
+    }
+    typename PROG::Shared S;
+    PROG::shared_init(S, smem, N, a.MM, SDL);
+    using LaneT = typename PROG::template LaneT<N>;
+    LaneT L;
+#ifdef GCS_PHASE_TIMING
+    __shared__ unsigned long long acc[64];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+    __syncthreads();
+    GpuExec<LaneT, RMODE> ex{L, (int)threadIdx.x, 0, acc};
+#else
+    GpuExec<LaneT, RMODE> ex{L, (int)threadIdx.x};
+#endif
+    PROG::template run<N, T, SDL>(ex, (int)blockIdx.x, a, S, rho, mu_scale);
+#ifdef GCS_PHASE_TIMING
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&g_phase_cycles[threadIdx.x], acc[threadIdx.x]);
+#endif
+}
+
 template <class PROG, int N, class T> static void launch_vertex_prog(const VertexLaunchDesc &d, hipStream_t s)
 {
     typename PROG::template Args<T> a;
@@ -277,7 +282,14 @@ template <class PROG, int N, class T> static void launch_vertex_prog(const Verte
     a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
     a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
     a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter;
-#define GCS_LAUNCH(RM, DL) hipLaunchKernelGGL((vertex_kernel<PROG, N, T, RM, DL>), dim3(d.n_waves), dim3(WAVE), d.lds_bytes, s, a, d.cb)
+    SpecialArgs<T> sp;
+    sp.count = d.n_special; sp.vtx = d.special_vtx; sp.kind = d.special_kind;
+    sp.inc_ptr = d.inc_ptr; sp.deg_in = d.deg_in; sp.inc_edge = d.inc_edge; sp.center = d.center;
+    sp.E = d.E; sp.NI = d.NI; sp.zedge = (const T *)d.zedge; sp.mu = (const T *)d.mu; sp.copy = (T *)d.copy;
+    sp.xv = d.xv; sp.zv = d.zv; sp.yv = d.yv; sp.eps_edge = d.eps_edge;
+    const unsigned grid = (unsigned)(d.n_waves + (d.n_special + WAVE - 1) / WAVE);
+    const int lds = std::max(d.lds_bytes, (int)(4 * MAX_SPECIAL_DEG * sizeof(double)));   // room for the special work arrays
+#define GCS_LAUNCH(RM, DL) hipLaunchKernelGGL((vertex_kernel<PROG, N, T, RM, DL>), dim3(grid), dim3(WAVE), lds, s, a, sp, d.cb)
     if constexpr (N == 2) {   // dense packing + wave shifts, and the stored dual directions, exist for the tuned dimension only
         if (!d.align_rows) { if (d.store_dl) GCS_LAUNCH(1, 1); else GCS_LAUNCH(1, 0); }
         else { if (d.store_dl) GCS_LAUNCH(0, 1); else GCS_LAUNCH(0, 0); }
@@ -290,21 +302,13 @@ template <class PROG, int N, class T> static void launch_vertex_prog(const Verte
 // vertex step for space dimension N: generic vertices (wavefront program) + special vertices (closed form)
 template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &d, hipStream_t s)
 {
-    if (d.n_waves > 0) {
+    if (d.n_waves + d.n_special > 0) {
         if constexpr (N == 2) {     // the m = 4 program exists for n = 2 only
             if (d.all_m4) launch_vertex_prog<ProgM4, N, T>(d, s);
             else launch_vertex_prog<ProgGeneric, N, T>(d, s);
         } else {
             launch_vertex_prog<ProgGeneric, N, T>(d, s);
         }
-    }
-    if (d.n_special > 0) {
-        SpecialArgs<T> a;
-        a.count = d.n_special; a.vtx = d.special_vtx; a.kind = d.special_kind;
-        a.inc_ptr = d.inc_ptr; a.deg_in = d.deg_in; a.inc_edge = d.inc_edge; a.center = d.center;
-        a.E = d.E; a.NI = d.NI; a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
-        a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.eps_edge = d.eps_edge;
-        hipLaunchKernelGGL((special_kernel<N, T>), dim3((d.n_special + 63) / 64), dim3(64), 0, s, a, d.cb);
     }
 }
 
