@@ -107,7 +107,7 @@ def main():
         ach = alg_bytes / (v_ms * 1e-3) / 1e9
         q = dev.query()
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01", "s10k_f32state_hbm_counters_v9.json")
+        prof = os.path.join(ROOT, "profiles", "r01", "s10k_f32state_hbm_counters_v10.json")
         if args.workload == "s10k" and os.path.exists(prof):
             # PMC counters cannot be read from inside this process: the per-launch figure is the one rocprofv3
             # collected for this same command line (separate --pmc passes, profiles/r01), FETCH_SIZE doubled
