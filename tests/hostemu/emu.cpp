@@ -97,6 +97,12 @@ extern "C" int EMU_NAME(int n, int V, int E, int NI, const int *inc_ptr, const i
     return 0;
 }
 
+// LDS slot size in doubles (layout rule checks)
+extern "C" int emu_slot_size(int n, int mm)
+{
+    return n == 2 ? SlotLayout<2>(mm).SIZE : (n == 3 ? SlotLayout<3>(mm).SIZE : SlotLayout<6>(mm).SIZE);
+}
+extern "C" int emu_group_base(int cur, int d, int d_in, int align) { return group_base(cur, d, d_in, align); }
 } // namespace emu_generic
 #undef EMU_NAME
 #define EMU_NAME emu_vertex_step_m4

@@ -134,3 +134,27 @@ def test_group_placement_dense_equals_aligned(emu, monkeypatch):
         assert np.array_equal(res["0"][k][5], res["1"][k][5])
         for a, b in zip(res["0"][k][:4], res["1"][k][:4]):
             assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+
+
+def test_layout_rules(emu):
+    """LDS slot stride = 2 mod 4 doubles for every facet count (lanes of different slots reading the same offset
+    must not meet on one bank: a stride of 0 mod 64 dwords cost 3-7 % on the lattices), and group_base() never lets
+    a side segment of an aligned group straddle a 16-lane row"""
+    for n in (2, 3, 6):
+        for mm in range(1, 40):
+            size = emu.emu_slot_size(n, mm)
+            assert size % 4 == 2, (n, mm, size)
+    for d in range(2, 33):
+        for d_in in range(1, d):
+            if d_in > 16 or d - d_in > 16:
+                continue
+            cur = 0
+            while True:
+                base = emu.emu_group_base(cur, d, d_in, 1)
+                if base < 0:
+                    break
+                assert base >= cur and base + d + 1 <= 64
+                assert (base + 1) >> 4 == (base + d_in) >> 4 and (base + d_in + 1) >> 4 == (base + d) >> 4
+                cur = base + d + 1
+            assert emu.emu_group_base(0, d, d_in, 1) >= 0
+            assert emu.emu_group_base(7, d, d_in, 0) == (7 if 7 + d + 1 <= 64 else -1)
