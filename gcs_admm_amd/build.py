@@ -10,15 +10,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 MAIN = os.path.join(CSRC, "gcsadmm.hip")
-DIMS = os.path.join(CSRC, "gcsadmm_dims.hip")
-# (source, object name, extra flags): the n = 3 / 6 kernels are one object per (dimension, state type)
-UNITS = [(MAIN, "gcsadmm.o", [])] + [(DIMS, f"gcsadmm_n{n}_f{32 if f else 64}.o", [f"-DGCS_DIM={n}", f"-DGCS_F32={f}"])
-                                     for n in (6, 3) for f in (0, 1)]
+WG = os.path.join(CSRC, "vertex_wg.hip")        # workgroup-cooperative vertex program (n = 2, 3, 6; own object)
 LP = os.path.join(CSRC, "polytope_lp.hip")      # batched tiny LPs for graph construction (own object, own dependencies)
-UNITS.append((LP, "polytope_lp.o", []))
+# (source, object name, extra flags)
+UNITS = [(MAIN, "gcsadmm.o", []), (WG, "vertex_wg.o", []), (LP, "polytope_lp.o", [])]
 HDR = os.path.join(ROOT, "include", "gcsadmm.h")
-DEPS = [MAIN, DIMS] + [os.path.join(CSRC, f) for f in ("vertex_program.h", "vertex_program.inc", "vertex_kernel.h")] + [HDR]
-UNIT_DEPS = {LP: [LP, HDR, os.path.join(CSRC, "polytope_lp_core.h")]}
+_c = lambda *names: [os.path.join(CSRC, f) for f in names]
+DEPS = [MAIN, HDR] + _c("vertex_program.h", "vertex_program.inc", "vertex_kernel.h", "special_vertex.h", "vertex_wg_launch.h")
+UNIT_DEPS = {LP: [LP, HDR] + _c("polytope_lp_core.h"),
+             WG: [WG, HDR] + _c("vertex_wg.h", "vertex_wg_launch.h", "special_vertex.h", "gcs_math.h")}
 OUT = os.path.join(HERE, "libgcsadmm.so")
 
 
@@ -30,8 +30,8 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Six objects compiled concurrently (the n = 6 instantiations take over a minute each), then linked."""
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + UNIT_DEPS[LP]):
+    """Three objects compiled concurrently, then linked."""
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + UNIT_DEPS[LP] + UNIT_DEPS[WG]):
         return OUT
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if verbose:
@@ -49,5 +49,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def build_timing() -> str:
+    """Diagnostic library (tools/wg_phase_timing.py): the workgroup program with its region stamps compiled in."""
+    out = os.path.join(HERE, "libgcsadmm_timing.so")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    build()
+    obj = os.path.join(HERE, "vertex_wg_timing.o")
+    subprocess.check_call([hipcc()] + flags + ["-DGCS_WG_TIMING", "-c", WG, "-o", obj])
+    objs = [os.path.join(HERE, n) for n in ("gcsadmm.o", "polytope_lp.o")] + [obj]
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
+
+
 if __name__ == "__main__":
+    if "--timing" in sys.argv:
+        print(build_timing())
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -38,6 +38,7 @@ __device__ __forceinline__ void gcs_stamp(int k)
 #define GCS_STAMP(k) gcs_stamp(k)
 #endif
 #include "vertex_kernel.h"
+#include "vertex_wg_launch.h"
 
 namespace {
 
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void cost_kernel(int V, int E, int n, const do
 struct gcsadmm_handle_s {
     int n = 0, V = 0, E = 0, NI = 0, NI_owned = 0, c = 0, MM = 0, dtype = 0, device = 0;
     int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
+    int n_wg = 0, wg_lds_bytes = 0;   // vertices solved by the workgroup program (vertex_wg.hip), LDS per workgroup
     bool all_m4 = false;      // every generic vertex has exactly 4 facets -> the register-dual program
     int align_rows = 0;       // group placement rule (group_base)
     int store_dl = 0;         // LDS holds the final dual directions of the facet rows (kernel template SDL)
@@ -243,7 +245,7 @@ struct gcsadmm_handle_s {
     // device buffers
     int *d_inc_ptr = nullptr, *d_deg_in = nullptr, *d_inc_edge = nullptr, *d_poly_ptr = nullptr;
     int *d_edge_inc_tail = nullptr, *d_edge_inc_head = nullptr;
-    int *d_wave_slot_ptr = nullptr, *d_wave_vtx = nullptr, *d_special_vtx = nullptr, *d_special_kind = nullptr;
+    int *d_wave_slot_ptr = nullptr, *d_wave_vtx = nullptr, *d_special_vtx = nullptr, *d_special_kind = nullptr, *d_wg_vtx = nullptr;
     double *d_poly_A = nullptr, *d_poly_bc = nullptr, *d_center = nullptr;
     uint8_t *d_inc_counted = nullptr, *d_edge_counted = nullptr;
     gcsadmm_control_block *d_cb = nullptr;
@@ -276,14 +278,31 @@ template <class U> static hipError_t upload(U **dst, const U *src, size_t count)
 
 static VertexLaunchDesc make_launch_desc(gcsadmm_handle h, const gcsadmm_state *st);
 
-// n = 2 is the tuned instantiation (plus the m = 4 program) and lives in this translation unit; n = 3 and n = 6
-// run the same wavefront program, functional but spilling heavily (the reduced border system has 4n+1
-// unknowns: 25 at n = 6), and are compiled separately (gcsadmm_dims.hip) because they take minutes to build
+// The generic vertices of a handle are split at create between the wavefront program (n = 2, degree <= 63: vertex_kernel.h)
+// and the workgroup program (everything else, and all vertices of small graphs: vertex_wg.hip); the closed-form vertices
+// ride in the trailing workgroups of whichever launch exists.
+static WgLaunchDesc make_wg_desc(gcsadmm_handle h, const gcsadmm_state *st, bool with_special)
+{
+    WgLaunchDesc d;
+    d.n = h->n; d.dtype = h->dtype; d.n_vtx = h->n_wg; d.n_special = with_special ? h->n_special : 0; d.lds_bytes = h->wg_lds_bytes;
+    d.vtx = h->d_wg_vtx; d.special_vtx = h->d_special_vtx; d.special_kind = h->d_special_kind;
+    d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
+    d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
+    d.E = h->E; d.NI = h->NI;
+    d.zedge = st->zedge; d.mu = st->mu; d.copy = st->copy; d.xv = st->xv; d.zv = st->zv; d.yv = st->yv;
+    d.counters = h->d_counters; d.cb = h->d_cb;
+    d.eps_edge = h->params.eps_edge; d.ipm_tol = h->params.ipm_tol; d.ipm_max_iter = h->params.ipm_max_iter;
+    return d;
+}
+
 template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
 {
-    const VertexLaunchDesc d = make_launch_desc(h, st);
-    if (h->n == 2) launch_vertex_dim<2, T>(d, s);
-    else gcsadmm_launch_vertex_hi(h->n, h->dtype, d, s);
+    const bool special_on_wave = h->n_waves > 0;
+    if (h->n_waves > 0) {
+        VertexLaunchDesc d = make_launch_desc(h, st);
+        launch_vertex_dim<2, T>(d, s);
+    }
+    if (h->n_wg > 0 || (!special_on_wave && h->n_special > 0)) gcsadmm_wg_launch(make_wg_desc(h, st, !special_on_wave), s);
     HIPCHK(h, hipGetLastError());
     return GCSADMM_OK;
 }
@@ -339,7 +358,7 @@ void gcsadmm_destroy(gcsadmm_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_inc_ptr, h->d_deg_in, h->d_inc_edge, h->d_poly_ptr, h->d_edge_inc_tail, h->d_edge_inc_head,
-                    h->d_wave_slot_ptr, h->d_wave_vtx, h->d_special_vtx, h->d_special_kind, h->d_poly_A, h->d_poly_bc,
+                    h->d_wave_slot_ptr, h->d_wave_vtx, h->d_special_vtx, h->d_special_kind, h->d_wg_vtx, h->d_poly_A, h->d_poly_bc,
                     h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -397,50 +416,87 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
             if (v != g->src && v != g->dst && !(s > 0.0)) return fail(GCSADMM_ERR_BAD_ARG, "center is not strictly inside its polytope");
         }
 
-    // classify vertices and pack the generic ones into wavefronts: d+1 lanes each
-    std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx;
-    const char *no_m4 = getenv("GCSADMM_NO_M4");                  // tuning knob: 1 = force the generic program
-    bool all_m4 = (n == 2) && !(no_m4 && atoi(no_m4) != 0);
-    for (int v = 0; v < V; ++v) {
+    // ---- classify the vertices ----
+    // closed form: s, t (points) and vertices no flow can cross; generic: an interior-point solve each.  A generic vertex
+    // goes to the WORKGROUP program (vertex_wg.hip) when the wavefront program cannot take it (n != 2, more than 63
+    // incident edges) or when the graph is small enough that latency, not throughput, decides (or on request).
+    auto is_special = [&](int v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
-        const bool generic = !(v == g->src || v == g->dst || din == 0 || d - din == 0);
-        if (generic && g->poly_ptr[v + 1] - g->poly_ptr[v] != 4) all_m4 = false;
-    }
-    // LDS per wavefront with / without room for the final dual directions (kernel template SDL): they save the
-    // update pass its facet rows (10k lattice +5 %) but must not cost a resident wavefront: kept only while four
-    // wavefronts still fit a CU's 160 KB (n = 2 only)
-    int store_dl = 0;
-    auto lds_need = [&](int slots) { return (size_t)(all_m4 ? gcs_m4::lds_doubles(n, MM, slots, store_dl) : gcs::lds_doubles(n, MM, slots, store_dl)) * 8; };
-    int slots_cap = MAX_SLOTS;
-    while (slots_cap > 1 && lds_need(slots_cap) > 160 * 1024) --slots_cap;
-    if (lds_need(slots_cap) > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
-    const int lds_cap = slots_cap;
-    // small graphs: spread the vertices over more wavefronts (a wavefront runs as long as its slowest
-    // vertex, and the chip has 1024 one-wave-per-SIMD slots to fill before packing pays)
-    {
-        int n_generic = 0;
-        for (int v = 0; v < V; ++v) {
-            const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
-            n_generic += !(v == g->src || v == g->dst || din == 0 || d - din == 0);
+        return v == g->src || v == g->dst || din == 0 || d - din == 0;
+    };
+    // s / t are treated as points (utils.py:12-28 turns them into boxes of half-width 1e-6): a terminal whose polytope has
+    // any extent would silently be replaced by its centre -- refuse it instead.
+    for (int term : {g->src, g->dst}) {
+        if (term < 0 || term >= V) continue;
+        // widest slack of a facet pair along any facet normal bounds the extent: b_j - a_j c over all facets is the distance
+        // (times |a_j|) from the centre to facet j; a point-like box has all of them <= ~1e-5
+        double ext = 0;
+        for (int j = g->poly_ptr[term]; j < g->poly_ptr[term + 1]; ++j) {
+            double nrm = 0;
+            for (int k = 0; k < n; ++k) nrm += g->poly_A[(size_t)j * n + k] * g->poly_A[(size_t)j * n + k];
+            ext = std::max(ext, std::fabs(bc[j]) / std::sqrt(nrm > 0 ? nrm : 1.0));
         }
-        const int want = std::max(1, (n_generic + 1023) / 1024);
-        slots_cap = std::min(slots_cap, want);
-        // tuning knob: vertices per wavefront (still bounded by the LDS limit found above)
-        if (const char *ov = getenv("GCSADMM_SLOTS")) slots_cap = std::max(1, std::min(lds_cap, atoi(ov)));
+        if (ext > 1e-5)
+            return fail(GCSADMM_ERR_UNSUPPORTED, "the source / target set must be a point (a box of half-width <= 1e-5 about `center`): "
+                                                 "its polytope is not used by the closed-form terminal update");
     }
+    int n_generic = 0;
+    for (int v = 0; v < V; ++v) n_generic += !is_special(v);
+    // Crossover of the two programs on n = 2 (measured on box lattices, profiles/r02): below ~1500 generic vertices one
+    // workgroup per vertex is faster (every CU holds several), above it the wavefront program's packing wins.
+    constexpr int WG_AUTO_MAX = 1536;
+    if (g->vertex_program < 0 || g->vertex_program > 2) return fail(GCSADMM_ERR_BAD_ARG, "vertex_program must be 0, 1 or 2");
+    const bool prefer_wg = g->vertex_program == 2 || (g->vertex_program == 0 && n_generic <= WG_AUTO_MAX);
+    std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx, wg_vtx;
+    std::vector<char> on_wave(V, 0);
+    int wg_lds = 0, MMw = 1;
+    bool all_m4 = (n == 2) && !g->wave_generic_rows;
     for (int v = 0; v < V; ++v) {
-        const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
-        if (v == g->src || v == g->dst || din == 0 || dout == 0) {
+        const int d = g->inc_ptr[v + 1] - g->inc_ptr[v];
+        const int m = g->poly_ptr[v + 1] - g->poly_ptr[v];
+        if (is_special(v)) {
             if (d > MAX_SPECIAL_DEG) return fail(GCSADMM_ERR_UNSUPPORTED, "terminal vertex degree above 256");
             special_vtx.push_back(v);
             special_kind.push_back(v == g->src ? 1 : (v == g->dst ? 2 : 0));
-        } else if (d + 1 > WAVE) {
-            return fail(GCSADMM_ERR_UNSUPPORTED, "vertex degree above 63 is not supported by the vertex kernel");
+        } else if (n != 2 || d + 1 > WAVE || prefer_wg) {
+            wg_vtx.push_back(v);
+            wg_lds = std::max(wg_lds, gcsadmm_wg_lds_bytes(n, d + 1, m));
+        } else {
+            on_wave[v] = 1;
+            MMw = std::max(MMw, m);
+            if (m != 4) all_m4 = false;
         }
+    }
+    if (wg_lds > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "a vertex sub-problem (degree x facets) does not fit the 160 KB of LDS of a CU");
+    // heaviest sub-problems first: the launch ends when its slowest workgroup does
+    std::stable_sort(wg_vtx.begin(), wg_vtx.end(), [&](int a, int b) {
+        const long ca = (long)(g->inc_ptr[a + 1] - g->inc_ptr[a] + 1) * (g->poly_ptr[a + 1] - g->poly_ptr[a]);
+        const long cb = (long)(g->inc_ptr[b + 1] - g->inc_ptr[b] + 1) * (g->poly_ptr[b + 1] - g->poly_ptr[b]);
+        return ca > cb;
+    });
+    MM = MMw;   // facet maximum over the wavefront program's vertices only (sizes its LDS)
+
+    // ---- wavefront program: pack its vertices into wavefronts, d+1 lanes each ----
+    // LDS per wavefront with / without room for the final dual directions (kernel template SDL): they save the
+    // update pass its facet rows (10k lattice +5 %) but must not cost a resident wavefront: kept only while four
+    // wavefronts still fit a CU's 160 KB
+    int store_dl = 0;
+    auto lds_need = [&](int slots) { return (size_t)(all_m4 ? gcs_m4::lds_doubles(n, MM, slots, store_dl) : gcs::lds_doubles(n, MM, slots, store_dl)) * 8; };
+    int slots_cap = MAX_SLOTS;
+    int n_on_wave = 0;
+    for (int v = 0; v < V; ++v) n_on_wave += on_wave[v];
+    if (n_on_wave > 0) {
+        while (slots_cap > 1 && lds_need(slots_cap) > 160 * 1024) --slots_cap;
+        if (lds_need(slots_cap) > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "facet count too large for LDS");
+        const int lds_cap = slots_cap;
+        // fewer vertices than wave slots: one vertex per wavefront (a wavefront runs as long as its slowest vertex)
+        const int want = std::max(1, (n_on_wave + 1023) / 1024);
+        slots_cap = std::min(slots_cap, want);
+        if (g->wave_slots > 0) slots_cap = std::max(1, std::min(lds_cap, (int)g->wave_slots));
     }
     // Group placement (vertex_program.inc group_base).  Aligned: no side segment straddles a 16-lane row, the
     // reductions use DPP row shifts (kernel RMODE 0).  Dense: groups back to back, more vertices per wavefront,
-    // reductions by chained wave shifts (RMODE 1, n = 2 only).  Aligned wins while the wavefronts fit the chip in
+    // reductions by chained wave shifts (RMODE 1).  Aligned wins while the wavefronts fit the chip in
     // two rounds (2 x 1024 one-wave-per-SIMD slots); beyond that throughput is per wavefront and dense wins
     // (10k lattice: 1 490 vs 1 440 it/s; 100k lattice: 241 vs 264 it/s).
     int max_slots_used = 0;
@@ -448,8 +504,8 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         wave_slot_ptr.assign(1, 0); wave_vtx.clear(); max_slots_used = 0;
         int lanes = 0, slots = 0;
         for (int v = 0; v < V; ++v) {
-            const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], dout = d - din;
-            if (v == g->src || v == g->dst || din == 0 || dout == 0) continue;
+            if (!on_wave[v]) continue;
+            const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
             int base = gcs::group_base(lanes, d, din, align);
             if (base < 0 || slots + 1 > slots_cap) {
                 wave_slot_ptr.push_back((int)wave_vtx.size());
@@ -464,9 +520,9 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     };
     int align_rows = 1;
     pack(1);
-    if (const char *ov = getenv("GCSADMM_ALIGN")) align_rows = atoi(ov) != 0;        // tuning knob
-    else if (n == 2 && (int)wave_slot_ptr.size() - 1 > 2048) align_rows = 0;
-    if (n != 2) align_rows = 1;                                                       // RMODE 1 is built for n = 2 only
+    if (g->wave_align == 1) align_rows = 1;
+    else if (g->wave_align == 2) align_rows = 0;
+    else if ((int)wave_slot_ptr.size() - 1 > 2048) align_rows = 0;
     if (!align_rows) pack(0);
     const int n_waves = (int)wave_slot_ptr.size() - 1;
 
@@ -477,14 +533,16 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
     h->slots_cap = std::max(1, max_slots_used);
     h->all_m4 = all_m4; h->align_rows = align_rows;
-    if (n == 2) {
+    if (n_waves > 0) {
         store_dl = 1;
         if (lds_need(h->slots_cap) > 40 * 1024) store_dl = 0;
-        if (const char *ov = getenv("GCSADMM_STORE_DL")) store_dl = atoi(ov) != 0;   // tuning knob
+        if (g->wave_store_dl == 1) store_dl = 1;
+        else if (g->wave_store_dl == 2) store_dl = 0;
         if (store_dl && lds_need(h->slots_cap) > 160 * 1024) store_dl = 0;
     }
     h->store_dl = store_dl;
-    h->lds_bytes = (int)lds_need(h->slots_cap);
+    h->lds_bytes = n_waves > 0 ? (int)lds_need(h->slots_cap) : 0;
+    h->n_wg = (int)wg_vtx.size(); h->wg_lds_bytes = wg_lds;
     h->nx = g->nx_global > 0 ? g->nx_global : (4.0 * n + 1) * (V + 2.0 * E);
     h->nmu = g->nmu_global > 0 ? g->nmu_global : (4.0 * n + 2) * E;
     h->edge_blocks = std::max(1, std::min((E + EDGE_BLOCK - 1) / EDGE_BLOCK, 2048));
@@ -506,6 +564,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_wave_vtx, wave_vtx.data(), wave_vtx.size());
     UP(d_special_vtx, special_vtx.data(), special_vtx.size());
     UP(d_special_kind, special_kind.data(), special_kind.size());
+    UP(d_wg_vtx, wg_vtx.data(), wg_vtx.size());
     UP(d_poly_A, g->poly_A, (size_t)MT * n);
     UP(d_poly_bc, bc.data(), MT);
     UP(d_center, g->center, (size_t)V * n);
@@ -517,10 +576,11 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_sums, (const double *)nullptr, 5);
 #undef UP
     if (h->lds_bytes > 48 * 1024) {
-        if (h->n == 2) e = h->dtype == GCSADMM_F64 ? set_lds_attr<2, double>(h->all_m4, h->lds_bytes) : set_lds_attr<2, float>(h->all_m4, h->lds_bytes);
-        else e = gcsadmm_lds_attr_hi(h->n, h->dtype, h->lds_bytes);
+        e = h->dtype == GCSADMM_F64 ? set_lds_attr<2, double>(h->all_m4, h->lds_bytes) : set_lds_attr<2, float>(h->all_m4, h->lds_bytes);
         if (e != hipSuccess) return bail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
+    if (h->wg_lds_bytes > 48 * 1024 && (e = gcsadmm_wg_set_lds(h->n, h->dtype, h->wg_lds_bytes)) != hipSuccess)
+        return bail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize, workgroup program)");
     *out = h;
     return GCSADMM_OK;
 }
@@ -646,12 +706,15 @@ int gcsadmm_debug_phase_cycles(unsigned long long *out64)
 }
 #endif
 
-gcsadmm_status gcsadmm_query(gcsadmm_handle h, int32_t *num_waves, int32_t *lds_bytes, int32_t *num_special)
+gcsadmm_status gcsadmm_query(gcsadmm_handle h, int32_t *num_waves, int32_t *lds_bytes, int32_t *num_special,
+                             int32_t *num_workgroup_vertices, int32_t *workgroup_lds_bytes)
 {
     if (!h) return GCSADMM_ERR_BAD_ARG;
     if (num_waves) *num_waves = h->n_waves;
     if (lds_bytes) *lds_bytes = h->lds_bytes;
     if (num_special) *num_special = h->n_special;
+    if (num_workgroup_vertices) *num_workgroup_vertices = h->n_wg;
+    if (workgroup_lds_bytes) *workgroup_lds_bytes = h->wg_lds_bytes;
     return GCSADMM_OK;
 }
 

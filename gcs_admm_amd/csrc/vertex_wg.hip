@@ -1,0 +1,94 @@
+// vertex_wg.hip -- gfx950 kernel of the workgroup-cooperative vertex program (vertex_wg.h): one 256-thread workgroup
+// per generic vertex, any space dimension the program is instantiated for (2, 3, 6), any degree and facet count that
+// fits the CU's 160 KB of LDS.  Trailing workgroups of the launch take the closed-form vertices (special_vertex.h).
+// Replaces admm_solver_v3.py:469-540 (one MOSEK solve per vertex through SolveInParallel) for the vertices routed here
+// by gcsadmm_create: small graphs, n = 3 / 6, degree > 63.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "special_vertex.h"
+#include "vertex_wg.h"
+#include "vertex_wg_launch.h"
+
+namespace {
+
+using namespace gcsadmm_k;
+using gcs_wg::WG_THREADS;
+
+template <int N, class T>
+__global__ __launch_bounds__(WG_THREADS, 2) void vertex_wg_kernel(gcs_wg::WgArgs<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (cb->status != GCSADMM_RUNNING) return;
+    const double rho = cb->rho, mu_scale = cb->mu_scale;
+    if ((int)blockIdx.x >= a.n_vtx) {      // closed-form vertices, one per thread
+        const int i = ((int)blockIdx.x - a.n_vtx) * WG_THREADS + (int)threadIdx.x;
+        if (i < sp.count) {
+            double *vals = smem + (sp.kind[i] == 2 ? 2 * MAX_SPECIAL_DEG : 0);   // source and target: own work arrays in LDS
+            special_body<N, T>(sp, i, rho, mu_scale, vals, vals + MAX_SPECIAL_DEG);
+        }
+        return;
+    }
+    int status = 0, iters = 0;
+    gcs_wg::wg_solve_vertex<N, T>(a, a.vtx[blockIdx.x], rho, mu_scale, smem, status, iters);
+    if (threadIdx.x == 0) {
+        if (status != 0) atomicAdd(&a.counters[0], 1);
+        atomicAdd(&a.counters[1], iters);
+    }
+}
+
+template <int N, class T> void launch(const WgLaunchDesc &d, hipStream_t s)
+{
+    gcs_wg::WgArgs<T> a;
+    a.n_vtx = d.n_vtx; a.vtx = d.vtx;
+    a.inc_ptr = d.inc_ptr; a.deg_in = d.deg_in; a.inc_edge = d.inc_edge; a.poly_ptr = d.poly_ptr;
+    a.poly_A = d.poly_A; a.poly_bc = d.poly_bc; a.center = d.center;
+    a.E = d.E; a.NI = d.NI;
+    a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
+    a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
+    a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter;
+    SpecialArgs<T> sp;
+    sp.count = d.n_special; sp.vtx = d.special_vtx; sp.kind = d.special_kind;
+    sp.inc_ptr = d.inc_ptr; sp.deg_in = d.deg_in; sp.inc_edge = d.inc_edge; sp.center = d.center;
+    sp.E = d.E; sp.NI = d.NI; sp.zedge = (const T *)d.zedge; sp.mu = (const T *)d.mu; sp.copy = (T *)d.copy;
+    sp.xv = d.xv; sp.zv = d.zv; sp.yv = d.yv; sp.eps_edge = d.eps_edge;
+    const unsigned grid = (unsigned)(d.n_vtx + (d.n_special + WG_THREADS - 1) / WG_THREADS);
+    if (grid == 0) return;
+    const int lds = std::max(d.lds_bytes, (int)(4 * MAX_SPECIAL_DEG * sizeof(double)));
+    hipLaunchKernelGGL((vertex_wg_kernel<N, T>), dim3(grid), dim3(WG_THREADS), lds, s, a, sp, d.cb);
+}
+
+template <int N, class T> hipError_t set_lds(int lds_bytes)
+{
+    return hipFuncSetAttribute((const void *)vertex_wg_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
+
+}  // namespace
+
+int gcsadmm_wg_lds_bytes(int n, int units, int facets) { return 8 * gcs_wg::wg_lds_doubles_n(n, units, facets); }
+
+hipError_t gcsadmm_wg_set_lds(int n, int dtype, int lds_bytes)
+{
+    const bool f64 = dtype == GCSADMM_F64;
+    if (n == 2) return f64 ? set_lds<2, double>(lds_bytes) : set_lds<2, float>(lds_bytes);
+    if (n == 3) return f64 ? set_lds<3, double>(lds_bytes) : set_lds<3, float>(lds_bytes);
+    return f64 ? set_lds<6, double>(lds_bytes) : set_lds<6, float>(lds_bytes);
+}
+
+void gcsadmm_wg_launch(const WgLaunchDesc &d, hipStream_t s)
+{
+    const bool f64 = d.dtype == GCSADMM_F64;
+    if (d.n == 2) { if (f64) launch<2, double>(d, s); else launch<2, float>(d, s); }
+    else if (d.n == 3) { if (f64) launch<3, double>(d, s); else launch<3, float>(d, s); }
+    else { if (f64) launch<6, double>(d, s); else launch<6, float>(d, s); }
+}
+
+#ifdef GCS_WG_TIMING
+extern "C" int gcsadmm_debug_wg_cycles(unsigned long long *cycles64, unsigned long long *counts64)
+{
+    int e = (int)hipMemcpyFromSymbol(cycles64, HIP_SYMBOL(gcs_wg::g_wg_cycles), 64 * sizeof(unsigned long long));
+    if (e == 0) e = (int)hipMemcpyFromSymbol(counts64, HIP_SYMBOL(gcs_wg::g_wg_counts), 64 * sizeof(unsigned long long));
+    return e;
+}
+#endif

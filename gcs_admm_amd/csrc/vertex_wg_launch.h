@@ -1,0 +1,32 @@
+// vertex_wg_launch.h -- host-side interface of the workgroup-cooperative vertex kernel (vertex_wg.hip), used by
+// gcsadmm.hip.  Plain pointers (device) and scalars; one object file per program keeps the builds parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gcsadmm.h"
+
+namespace gcsadmm_k {
+
+struct WgLaunchDesc {
+    int n, dtype;                   // space dimension (2, 3, 6), GCSADMM_F64 / GCSADMM_F32
+    int n_vtx, n_special, lds_bytes;
+    const int *vtx;                 // [n_vtx] generic vertices of this launch, one workgroup each
+    const int *special_vtx, *special_kind;   // trailing workgroups (may be empty: n_special = 0)
+    const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
+    const double *poly_A, *poly_bc, *center;
+    int E, NI;
+    void *zedge, *mu, *copy;
+    double *xv, *zv, *yv;
+    int *counters;
+    const gcsadmm_control_block *cb;
+    double eps_edge, ipm_tol;
+    int ipm_max_iter;
+};
+
+}  // namespace gcsadmm_k
+
+// LDS bytes one workgroup needs for a vertex with `units` = degree + 1 and `facets` facets
+int gcsadmm_wg_lds_bytes(int n, int units, int facets);
+// raise the dynamic-LDS limit of the instantiation (needed above 48 KB)
+hipError_t gcsadmm_wg_set_lds(int n, int dtype, int lds_bytes);
+void gcsadmm_wg_launch(const gcsadmm_k::WgLaunchDesc &d, hipStream_t s);

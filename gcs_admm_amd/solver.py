@@ -37,7 +37,10 @@ class GraphDesc(C.Structure):
                 ("poly_ptr", C.c_void_p), ("poly_A", C.c_void_p), ("poly_b", C.c_void_p), ("center", C.c_void_p),
                 ("src", C.c_int32), ("dst", C.c_int32), ("state_dtype", C.c_int32), ("device", C.c_int32),
                 ("inc_counted", C.c_void_p), ("edge_counted", C.c_void_p),
-                ("nx_global", C.c_double), ("nmu_global", C.c_double)]
+                ("nx_global", C.c_double), ("nmu_global", C.c_double),
+                # schedule of the vertex step (0 = automatic): see include/gcsadmm.h
+                ("vertex_program", C.c_int32), ("wave_slots", C.c_int32), ("wave_align", C.c_int32),
+                ("wave_store_dl", C.c_int32), ("wave_generic_rows", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -99,7 +102,8 @@ class DeviceSolver:
 
     def __init__(self, graph: GcsGraph, state_dtype: str = "f64", device: Optional[int] = None,
                  num_incidences: Optional[int] = None, inc_counted=None, edge_counted=None,
-                 nx_global: float = 0.0, nmu_global: float = 0.0):
+                 nx_global: float = 0.0, nmu_global: float = 0.0, program: str = "auto", wave_slots: int = 0,
+                 wave_align: int = 0, wave_store_dl: int = 0, wave_generic_rows: int = 0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the ADMM loop only runs on the GPU (no CPU fallback)")
@@ -125,7 +129,9 @@ class DeviceSolver:
                          _np_ptr(k[3]), _np_ptr(k[4]), _np_ptr(k[5]), _np_ptr(k[6]), _np_ptr(k[7]), _np_ptr(k[8]),
                          g.src, g.dst, self.dtype_code, self.device_index,
                          _np_ptr(ic) if ic is not None else None, _np_ptr(ec) if ec is not None else None,
-                         float(nx_global), float(nmu_global))
+                         float(nx_global), float(nmu_global),
+                         {"auto": 0, "wavefront": 1, "workgroup": 2}[program], int(wave_slots), int(wave_align),
+                         int(wave_store_dl), int(wave_generic_rows), 0)
         h = C.c_void_p()
         st = self.lib.gcsadmm_create(C.byref(desc), C.byref(h))
         if st != 0:
@@ -207,9 +213,10 @@ class DeviceSolver:
         return cb
 
     def query(self):
-        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        self._check(self.lib.gcsadmm_query(self.h, C.byref(a), C.byref(b), C.byref(c)), "gcsadmm_query")
-        return dict(num_waves=a.value, lds_bytes=b.value, num_special=c.value)
+        a, b, c, d, e = (C.c_int32(0) for _ in range(5))
+        self._check(self.lib.gcsadmm_query(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)), "gcsadmm_query")
+        return dict(num_waves=a.value, lds_bytes=b.value, num_special=c.value, num_workgroup_vertices=d.value,
+                    workgroup_lds_bytes=e.value)
 
     def cost(self) -> float:
         eps = self.params.eps_edge if self.params is not None else 1e-4

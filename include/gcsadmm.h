@@ -42,7 +42,7 @@ extern "C" {
 typedef enum gcsadmm_status {
     GCSADMM_OK = 0,
     GCSADMM_ERR_BAD_ARG = 1,        /* null pointer, negative size, inconsistent CSR, unsupported n */
-    GCSADMM_ERR_UNSUPPORTED = 2,    /* degree or facet count above the kernel's limits */
+    GCSADMM_ERR_UNSUPPORTED = 2,    /* a vertex whose sub-problem does not fit the CU's LDS; 's' / 't' that are not points */
     GCSADMM_ERR_HIP = 3,            /* a HIP runtime call failed */
     GCSADMM_ERR_NO_DEVICE = 4
 } gcsadmm_status;
@@ -53,7 +53,7 @@ enum { GCSADMM_F64 = 0, GCSADMM_F32 = 1 };
 enum { GCSADMM_RUNNING = -1, GCSADMM_CONVERGED = 0, GCSADMM_MAX_IT = 1, GCSADMM_DIVERGED = 2 };
 
 typedef struct gcsadmm_graph_desc {
-    int32_t n;                       /* space dimension: 2 (tuned), 3 or 6 (functional, not yet tuned) */
+    int32_t n;                       /* space dimension: 2, 3 or 6 */
     int32_t num_vertices;            /* vertices whose sub-problem this handle solves */
     int32_t num_edges;               /* directed edges this handle updates */
     int32_t num_incidences;          /* NI: columns of copy/mu; >= inc_ptr[num_vertices]; the surplus are
@@ -74,6 +74,17 @@ typedef struct gcsadmm_graph_desc {
     const uint8_t *edge_counted;     /* [E]  or NULL(=all 1): this handle counts the edge in the norms */
     double nx_global, nmu_global;    /* lengths of the reference's x / mu vectors for eps_pri / eps_dual
                                         (admm_solver_v3.py:605-614); 0 = derive from this handle's sizes */
+    /* Schedule of the vertex step (all 0 = automatic).  Two programs solve the same sub-problem with the same
+     * interior-point method: the WAVEFRONT program (n = 2, degree <= 63; several vertices per 64-lane wavefront,
+     * highest throughput on large graphs) and the WORKGROUP program (any n, degree and facet count that fits LDS;
+     * one 256-thread workgroup per vertex, lowest latency: small graphs).  These fields replace what used to be
+     * process-global environment knobs; they never change WHAT is computed, only how it is laid out on the chip. */
+    int32_t vertex_program;          /* 0 auto, 1 wavefront (where it applies), 2 workgroup */
+    int32_t wave_slots;              /* wavefront program: vertices per wavefront (0 auto) */
+    int32_t wave_align;              /* wavefront program: 0 auto, 1 row-aligned groups, 2 dense packing */
+    int32_t wave_store_dl;           /* wavefront program: 0 auto, 1 keep the facet-row dual directions in LDS, 2 recompute */
+    int32_t wave_generic_rows;       /* wavefront program: 1 = any-facet-count variant even when every polytope has 4 facets */
+    int32_t reserved0;
 } gcsadmm_graph_desc;
 
 typedef struct gcsadmm_params {
@@ -147,9 +158,10 @@ gcsadmm_status gcsadmm_read_control(gcsadmm_handle h, gcsadmm_control_block *out
 /* sum_v |z_v[:n] - z_v[n:]| + eps_edge * sum_e y_e over counted edges -> cost_dev[0] (f64, device). */
 gcsadmm_status gcsadmm_cost(gcsadmm_handle h, const gcsadmm_state *st, double eps_edge, double *cost_dev, void *stream);
 
-/* Kernel-side facts for benchmarking: number of vertex-kernel workgroups, LDS bytes per workgroup,
- * and the last measured average duration (ms) of the vertex kernel between two events, see bench.py */
-gcsadmm_status gcsadmm_query(gcsadmm_handle h, int32_t *num_waves, int32_t *lds_bytes, int32_t *num_special);
+/* Kernel-side facts for benchmarking (any pointer may be NULL): workgroups of the wavefront program and their LDS
+ * bytes, closed-form vertices, workgroups (= vertices) of the workgroup program and their LDS bytes. */
+gcsadmm_status gcsadmm_query(gcsadmm_handle h, int32_t *num_waves, int32_t *lds_bytes, int32_t *num_special,
+                             int32_t *num_workgroup_vertices, int32_t *workgroup_lds_bytes);
 
 /* As gcsadmm_run, but every kernel launch is bracketed by HIP events recorded on `stream`; after the
  * k iterations the call synchronises and returns the summed device time (ms) and launch count of the

@@ -922,13 +922,19 @@ int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double 
         }
         const int p0 = G->poly_ptr[v], m = G->poly_ptr[v + 1] - p0;
         dbg_vertex = v;
+        double xv_t[2 * MAXN], zv_t[2 * MAXN], yv_t = 0.0;
         int r = oracle_solve_vertex(n, m, G->poly_A + (size_t)p0 * n, G->poly_b + p0, G->center + (size_t)v * n,
-                                    d, d_in, v == G->src, v == G->dst, T, rho, ip, C,
-                                    xv + (size_t)v * 2 * n, zv + (size_t)v * 2 * n, yv + v);
+                                    d, d_in, v == G->src, v == G->dst, T, rho, ip, C, xv_t, zv_t, &yv_t);
         if (r < 0) fails += 1; else iters += r;
         if (g_iters_out) g_iters_out[v] = r;
-        for (int k = 0; k < d; ++k)
-            for (int w = 0; w < c; ++w) copy[w * NI + lo + k] = C[w * d + k];
+        /* a failed inner solve keeps the vertex's previous copy columns and outputs (the reference's intent at
+         * admm_solver_v3.py:524-538; its own branch would raise) and is counted */
+        if (r >= 0) {
+            for (int k = 0; k < 2 * n; ++k) { xv[(size_t)v * 2 * n + k] = xv_t[k]; zv[(size_t)v * 2 * n + k] = zv_t[k]; }
+            yv[v] = yv_t;
+            for (int k = 0; k < d; ++k)
+                for (int w = 0; w < c; ++w) copy[w * NI + lo + k] = C[w * d + k];
+        }
         if (T != Tst) free(T);
     }
     if (ipm_iters_total) *ipm_iters_total += iters;

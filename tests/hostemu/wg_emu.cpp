@@ -1,0 +1,72 @@
+// HOST build of the workgroup-cooperative vertex program (gcs_admm_amd/csrc/vertex_wg.h).
+// DEBUG / TEST HARNESS ONLY: with WG_FOR a plain loop and WG_SYNC a no-op each parallel region runs its tasks
+// serially, which equals the GPU execution as long as the tasks of a region are independent.  Built twice
+// (tasks in ascending order / -DGCS_WG_REVERSE descending order): equal results are evidence of that independence.
+// Unwritten LDS is poisoned with NaN.  Never shipped, never timed; the product has no path into it.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "vertex_wg.h"
+
+#ifdef GCS_WG_REVERSE
+#define EMU_FN wg_emu_vertex_step_rev
+#define EMU_LDS wg_emu_lds_doubles_rev
+#else
+#define EMU_FN wg_emu_vertex_step
+#define EMU_LDS wg_emu_lds_doubles
+#endif
+
+template <int N>
+static void run_all(const gcs_wg::WgArgs<double> &a, double rho, double mu_scale, int lds, int *status, int *iters)
+{
+    std::vector<double> smem(lds);
+    for (int w = 0; w < a.n_vtx; ++w) {
+        std::fill(smem.begin(), smem.end(), 0.0 / 0.0);
+        int st = -9, it = 0;
+        gcs_wg::wg_solve_vertex<N, double>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
+        status[a.vtx[w]] = st; iters[a.vtx[w]] = it;
+        a.counters[0] += st != 0; a.counters[1] += it;
+    }
+}
+
+extern "C" int EMU_LDS(int n, int U, int m) { return gcs_wg::wg_lds_doubles_n(n, U, m); }
+
+// one vertex step over the generic vertices of a graph; special vertices (s, t, no-flow) are left untouched
+extern "C" int EMU_FN(int n, int V, int E, int NI, const int *inc_ptr, const int *inc_edge, const int *inc_out,
+                      const int *poly_ptr, const double *poly_A, const double *poly_b, const double *center,
+                      int src, int dst, const double *zedge, const double *mu, double rho, double mu_scale,
+                      double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv, double *zv,
+                      double *yv, int *counters, int *is_generic, int *status, int *iters)
+{
+    if (n != 2 && n != 3 && n != 6) return 1;
+    std::vector<int> deg_in(V, 0), vtx;
+    int lds = 0;
+    for (int v = 0; v < V; ++v) {
+        for (int k = inc_ptr[v]; k < inc_ptr[v + 1]; ++k) deg_in[v] += !inc_out[k];
+        const int d = inc_ptr[v + 1] - inc_ptr[v];
+        is_generic[v] = !(v == src || v == dst || deg_in[v] == 0 || d - deg_in[v] == 0);
+        status[v] = 0; iters[v] = 0;
+        if (is_generic[v]) {
+            vtx.push_back(v);
+            lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, d + 1, poly_ptr[v + 1] - poly_ptr[v]));
+        }
+    }
+    std::vector<double> bc(poly_ptr[V]);
+    for (int v = 0; v < V; ++v)
+        for (int j = poly_ptr[v]; j < poly_ptr[v + 1]; ++j) {
+            double s = poly_b[j];
+            for (int k = 0; k < n; ++k) s -= poly_A[(size_t)j * n + k] * center[(size_t)v * n + k];
+            bc[j] = s;
+        }
+    gcs_wg::WgArgs<double> a;
+    a.n_vtx = (int)vtx.size(); a.vtx = vtx.data();
+    a.inc_ptr = inc_ptr; a.deg_in = deg_in.data(); a.inc_edge = inc_edge; a.poly_ptr = poly_ptr;
+    a.poly_A = poly_A; a.poly_bc = bc.data(); a.center = center; a.E = E; a.NI = NI;
+    a.zedge = zedge; a.mu = mu; a.copy = copy; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
+    a.eps_edge = eps_edge; a.ipm_tol = ipm_tol; a.ipm_max_iter = ipm_max_iter;
+    if (n == 2) run_all<2>(a, rho, mu_scale, lds, status, iters);
+    else if (n == 3) run_all<3>(a, rho, mu_scale, lds, status, iters);
+    else run_all<6>(a, rho, mu_scale, lds, status, iters);
+    return 0;
+}

@@ -26,13 +26,26 @@ def test_library_exports_header():
     assert sorted(solver.EXPORTS) == syms
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """sizes and field offsets of the ctypes mirrors equal what a C compiler derives from include/gcsadmm.h"""
+    import subprocess
     from gcs_admm_amd import solver
-    # sizes implied by the header's field lists on LP64
-    assert ctypes.sizeof(solver.GraphDesc) == 4 * 4 + 9 * 8 + 4 * 4 + 2 * 8 + 2 * 8
-    assert ctypes.sizeof(solver.Params) == 4 * 8 + 2 * 4 + 4 * 8 + 2 * 4
-    assert ctypes.sizeof(solver.State) == 6 * 8
-    assert ctypes.sizeof(solver.ControlBlock) == 11 * 8 + 4 * 4
+    pairs = [("gcsadmm_graph_desc", solver.GraphDesc), ("gcsadmm_params", solver.Params), ("gcsadmm_state", solver.State),
+             ("gcsadmm_control_block", solver.ControlBlock)]
+    lines = []
+    for cname, ct in pairs:
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gcsadmm.h"\nint main(void){' + "".join(lines) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in pairs:
+        assert int(got[cname]) == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
 
 
 def test_no_cpu_fallback():

@@ -28,9 +28,12 @@ def torch_gpu():
     return torch
 
 
-def _solver(g, dtype="f64"):
+def _solver(g, dtype="f64", program="auto"):
     from gcs_admm_amd.solver import DeviceSolver
-    return DeviceSolver(g, dtype, device=0)
+    return DeviceSolver(g, dtype, device=0, program=program)
+
+
+PROGRAMS = ["wavefront", "workgroup"]
 
 
 def _generic_mask(g):
@@ -41,12 +44,13 @@ def _generic_mask(g):
     return gen
 
 
+@pytest.mark.parametrize("program", PROGRAMS)
 @pytest.mark.parametrize("name", ["benchmark1", "benchmark4", "test_autogen2", "benchmark3"])
-def test_step_by_step_against_oracle(torch_gpu, oracle_lib, name):
+def test_step_by_step_against_oracle(torch_gpu, oracle_lib, name, program):
     torch = torch_gpu
     case, g = load_fixture(name)
     o = oracle_lib.Oracle(g, ipm_tol=1e-9)
-    d = _solver(g)
+    d = _solver(g, program=program)
     d.reset()
     diffs = []
     for it in range(30):
@@ -76,11 +80,12 @@ def test_step_by_step_against_oracle(torch_gpu, oracle_lib, name):
     assert cb.status == -1 and cb.it == 1       # control was never run here
 
 
+@pytest.mark.parametrize("program", PROGRAMS)
 @pytest.mark.parametrize("name", BENCHMARKS)
-def test_full_run_against_oracle_and_reference_record(torch_gpu, oracle_lib, name):
+def test_full_run_against_oracle_and_reference_record(torch_gpu, oracle_lib, name, program):
     case, g = load_fixture(name)
     gold = case["golden_v3"]
-    d = _solver(g)
+    d = _solver(g, program=program)
     res = d.solve()
     ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run()
     assert res["status"] == "converged" and res["inner_failures"] == 0
@@ -256,18 +261,26 @@ def test_high_degree_vertex_and_degree_limit(torch_gpu, oracle_lib):
     As, bs, n = star_case(24)
     g = graph_from_sets(As, bs, n)
     assert np.diff(g.inc_ptr).max() >= 40
-    d = _solver(g)
+    d = _solver(g, program="wavefront")
     res = d.solve(max_it=80, eps_abs=0.0, eps_rel=0.0)
     ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=80, eps_abs=0.0, eps_rel=0.0)
     assert res["inner_failures"] == 0
     for key in ("pri_res_seq", "dual_res_seq"):
         assert np.all(np.abs(res[key] - ora[key]) <= 2e-4 + 1e-3 * np.abs(ora[key])), key
-    # more than 63 incident edges at one vertex is refused with a documented code, not a crash
+    # more than 63 incident edges at one vertex (beyond one wavefront): that vertex runs the workgroup program
+    # (admm_solver_v3.py:371 takes any I_v_in[v] + I_v_out[v])
     As, bs, n = star_case(40)
     g2 = graph_from_sets(As, bs, n)
     assert np.diff(g2.inc_ptr).max() > 63
-    with pytest.raises(solver.GcsAdmmError, match="degree"):
-        _solver(g2)
+    for program in ("wavefront", "auto"):
+        d2 = _solver(g2, program=program)
+        q = d2.query()
+        assert q["num_workgroup_vertices"] >= 1 and (program != "wavefront" or q["num_waves"] >= 1)
+        res = d2.solve(max_it=60, eps_abs=0.0, eps_rel=0.0)
+        ora = oracle_lib.Oracle(g2, ipm_tol=1e-9).run(max_it=60, eps_abs=0.0, eps_rel=0.0)
+        assert res["inner_failures"] == 0
+        for key in ("pri_res_seq", "dual_res_seq"):
+            assert np.all(np.abs(res[key] - ora[key]) <= 2e-4 + 1e-3 * np.abs(ora[key])), key
 
 
 def test_degenerate_graphs(torch_gpu, oracle_lib):
@@ -294,20 +307,24 @@ def test_degenerate_graphs(torch_gpu, oracle_lib):
     assert np.all(np.abs(res["pri_res_seq"] - ora["pri_res_seq"]) <= 2e-4 + 1e-3 * np.abs(ora["pri_res_seq"]))
 
 
-@pytest.mark.parametrize("knobs", [{"GCSADMM_ALIGN": "0", "GCSADMM_SLOTS": "7"}, {"GCSADMM_ALIGN": "1", "GCSADMM_SLOTS": "7"},
-                                   {"GCSADMM_ALIGN": "0", "GCSADMM_SLOTS": "7", "GCSADMM_NO_M4": "1"},
-                                   {"GCSADMM_ALIGN": "1", "GCSADMM_SLOTS": "3", "GCSADMM_NO_M4": "1"},
-                                   {"GCSADMM_ALIGN": "1", "GCSADMM_STORE_DL": "0"}, {"GCSADMM_ALIGN": "0", "GCSADMM_STORE_DL": "0", "GCSADMM_NO_M4": "1"}])
-def test_packing_and_reduction_modes(torch_gpu, oracle_lib, monkeypatch, knobs):
-    """every schedule of the vertex kernel (dense packing + chained wave shifts, row-aligned packing + DPP row
-    shifts, generic and 4-facet program, 3 or 7 vertices per wavefront, update pass from stored directions or
-    recomputed rows) gives the oracle's vertex step"""
+@pytest.mark.parametrize("knobs", [dict(wave_align=2, wave_slots=7), dict(wave_align=1, wave_slots=7),
+                                   dict(wave_align=2, wave_slots=7, wave_generic_rows=1),
+                                   dict(wave_align=1, wave_slots=3, wave_generic_rows=1),
+                                   dict(wave_align=1, wave_store_dl=2), dict(wave_align=2, wave_store_dl=2, wave_generic_rows=1),
+                                   dict(program="workgroup")])
+def test_packing_and_reduction_modes(torch_gpu, oracle_lib, knobs):
+    """every schedule of the vertex step (wavefront program: dense packing + chained wave shifts, row-aligned packing + DPP
+    row shifts, generic and 4-facet variant, 3 or 7 vertices per wavefront, update pass from stored directions or
+    recomputed rows; workgroup program) gives the oracle's vertex step.  The schedule is part of the graph descriptor
+    (include/gcsadmm.h), not of the process environment."""
     torch = torch_gpu
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)                     # read by gcsadmm_create
+    from gcs_admm_amd.solver import DeviceSolver
     g = lattice_boxes(14, 11, seed=7)
     o = oracle_lib.Oracle(g, ipm_tol=1e-9)
-    d = _solver(g)
+    kw = dict(program="wavefront"); kw.update(knobs)
+    d = DeviceSolver(g, "f64", device=0, **kw)
+    q = d.query()
+    assert (q["num_workgroup_vertices"] > 0) == (kw["program"] == "workgroup") and (q["num_waves"] > 0) == (kw["program"] == "wavefront")
     d.reset()
     for it in range(12):
         d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu.copy_(torch.from_numpy(o.mu))
