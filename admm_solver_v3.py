@@ -10,7 +10,6 @@ import argparse
 import importlib
 import os
 import sys
-import time
 
 import numpy as np
 
@@ -49,9 +48,10 @@ def main(argv=None):
     print(f"E: {E}")
     dev = DeviceSolver(g, "f64")
     MAX_IT = 1000
-    t0 = time.time()
-    res = dev.solve(max_it=MAX_IT)
-    wall = time.time() - t0
+    res = dev.solve(max_it=MAX_IT, timed=True)
+    # solve_time keeps the reference's meaning (admm_solver_v3.py:489-491, 579-585: the vertex solves and the edge update,
+    # nothing else): device time of the vertex-step and edge-step kernels.  The wall time of the whole loop is reported too.
+    solve_time, wall = res["device_time_s"], res["wall_time_s"]
     it = res["iterations"]
     pri, dual = res["pri_res_seq"], res["dual_res_seq"]
     for k in range(100, min(it, MAX_IT) + 1, 100):
@@ -71,7 +71,8 @@ def main(argv=None):
     cost = compute_cost(z_v_sol, y_e_e_sol)
     print(f"x_v: {x_v_sol}")
     print(f"y_v: {y_v_sol}")
-    print(f"Total solve time: {wall} s.")
+    print(f"Total solve time: {solve_time} s.")
+    print(f"Loop wall time: {wall} s.  Inner solver failures: {res['inner_failures']}")
     print(f"Cost before rounding: {cost}")
     print("===============================================================")
     print("POST-ROUNDING")
@@ -84,8 +85,9 @@ def main(argv=None):
     if args.show_plot == True:  # noqa: E712  (string semantics on purpose)
         visualize_results(As, bs, x_v_sol, y_v_sol, x_v_rounded, y_v_rounded)
     os.makedirs("benchmark_data", exist_ok=True)
-    save_data(f"benchmark_data/admm_solver_v3_{args.test_file}.pkl", As, bs, wall, cost, x_v_sol, y_v_sol,
-              x_v_rounded, y_v_rounded, True, it, res["rho_seq"], res["pri_res_seq"], res["dual_res_seq"])
+    save_data(f"benchmark_data/admm_solver_v3_{args.test_file}.pkl", As, bs, solve_time, cost, x_v_sol, y_v_sol,
+              x_v_rounded, y_v_rounded, True, it, res["rho_seq"], res["pri_res_seq"], res["dual_res_seq"],
+              loop_wall_time=wall, inner_failures=res["inner_failures"])
     return res
 
 

@@ -11,6 +11,8 @@
 //                        (edge_kernel<T, true>, finalize_control_kernel): fewer launches per iteration
 //   cost_kernel<T>       GCS_utils.py:184-211
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -203,6 +205,35 @@ __global__ __launch_bounds__(256) void finalize_control_kernel(const double *par
     if (threadIdx.x == 0) control_body(cb, sums, cp, counters, trace);
 }
 
+// halo of a vertex partition: copies of the cut edges' coupled words, packed per neighbour as [c][columns of that peer]
+// (one contiguous message per peer).  base[j] / stride[j]: where column j of the flat send (recv) list sits in the buffer.
+template <class T>
+__global__ __launch_bounds__(256) void halo_pack_kernel(int c, int ncols, int NI, const int *cols, const int *base, const int *stride,
+                                                        const T *copy, T *buf, const gcsadmm_control_block *cb)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= c * ncols) return;
+    const int w = t / ncols, j = t - w * ncols;
+    buf[base[j] + w * stride[j]] = copy[(size_t)w * NI + cols[j]];
+}
+template <class T>
+__global__ __launch_bounds__(256) void halo_unpack_kernel(int c, int ncols, int NI, const int *cols, const int *base, const int *stride,
+                                                          const T *buf, T *copy, const gcsadmm_control_block *cb)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= c * ncols) return;
+    const int w = t / ncols, j = t - w * ncols;
+    copy[(size_t)w * NI + cols[j]] = buf[base[j] + w * stride[j]];
+}
+// sums[5] := this partition's inner-failure count (summed with the norms by the all-reduce)
+__global__ void fails_to_sums_kernel(double *sums, const int *counters, const gcsadmm_control_block *cb)
+{
+    if (cb->status != GCSADMM_RUNNING) return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) sums[5] = (double)counters[0];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void cost_kernel(int V, int E, int n, const double *zv, const T *zedge,
                                                    const uint8_t *edge_counted, double eps_edge, double *cost)
@@ -256,6 +287,30 @@ struct gcsadmm_handle_s {
 };
 
 static std::string g_create_error;
+
+// Entry points work on the handle's device and leave the caller's current device as they found it (a process may hold
+// handles on several devices, and PyTorch tracks "its" current device on its own).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        int cur = -1;
+        err = hipGetDevice(&cur);
+        if (err == hipSuccess && cur != dev) { err = hipSetDevice(dev); if (err == hipSuccess) prev = cur; }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define USE_DEVICE(h)                                                                                \
+    DeviceGuard device_guard_((h)->device);                                                          \
+    do {                                                                                             \
+        if (device_guard_.err != hipSuccess) {                                                       \
+            (h)->err = std::string("hipSetDevice: ") + hipGetErrorString(device_guard_.err);        \
+            return GCSADMM_ERR_HIP;                                                                  \
+        }                                                                                            \
+    } while (0)
 
 #define HIPCHK(h, call)                                                                              \
     do {                                                                                             \
@@ -356,7 +411,7 @@ const char *gcsadmm_last_error(gcsadmm_handle h) { return h ? h->err.c_str() : g
 void gcsadmm_destroy(gcsadmm_handle h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard device_guard_(h->device);
     void *ptrs[] = {h->d_inc_ptr, h->d_deg_in, h->d_inc_edge, h->d_poly_ptr, h->d_edge_inc_tail, h->d_edge_inc_head,
                     h->d_wave_slot_ptr, h->d_wave_vtx, h->d_special_vtx, h->d_special_kind, h->d_wg_vtx, h->d_poly_A, h->d_poly_bc,
                     h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums};
@@ -552,7 +607,8 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         return GCSADMM_ERR_HIP;
     };
     hipError_t e;
-    if ((e = hipSetDevice(g->device)) != hipSuccess) return bail(e, "hipSetDevice");
+    DeviceGuard device_guard_(g->device);
+    if ((e = device_guard_.err) != hipSuccess) return bail(e, "hipSetDevice");
 #define UP(dst, src, cnt) if ((e = upload(&h->dst, src, (size_t)(cnt))) != hipSuccess) return bail(e, "upload " #dst)
     UP(d_inc_ptr, g->inc_ptr, V + 1);
     UP(d_deg_in, deg_in.data(), V);
@@ -592,7 +648,7 @@ gcsadmm_status gcsadmm_reset(gcsadmm_handle h, const gcsadmm_params *p, void *st
     h->params = *p; h->params_set = true;
     gcsadmm_control_block cb{};
     cb.rho = p->rho; cb.mu_scale = 1.0; cb.it = 1; cb.status = GCSADMM_RUNNING;
-    HIPCHK(h, hipSetDevice(h->device));
+    USE_DEVICE(h);
     HIPCHK(h, hipMemcpyAsync(h->d_cb, &cb, sizeof(cb), hipMemcpyHostToDevice, (hipStream_t)stream));
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), (hipStream_t)stream));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));   // cb is a stack object
@@ -602,21 +658,21 @@ gcsadmm_status gcsadmm_reset(gcsadmm_handle h, const gcsadmm_params *p, void *st
 gcsadmm_status gcsadmm_vertex_step(gcsadmm_handle h, const gcsadmm_state *st, void *stream)
 {
     if (!state_ok(h, st)) return GCSADMM_ERR_BAD_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    USE_DEVICE(h);
     return h->dtype == GCSADMM_F64 ? launch_vertex<double>(h, st, (hipStream_t)stream) : launch_vertex<float>(h, st, (hipStream_t)stream);
 }
 
 gcsadmm_status gcsadmm_edge_step(gcsadmm_handle h, const gcsadmm_state *st, double *sums_dev, void *stream)
 {
     if (!state_ok(h, st) || !sums_dev) return GCSADMM_ERR_BAD_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    USE_DEVICE(h);
     return h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, sums_dev, (hipStream_t)stream) : launch_edge<float>(h, st, sums_dev, (hipStream_t)stream);
 }
 
 gcsadmm_status gcsadmm_control(gcsadmm_handle h, const double *sums_dev, double *trace_dev, void *stream)
 {
     if (!h || !sums_dev || !h->params_set) return GCSADMM_ERR_BAD_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    USE_DEVICE(h);
     const gcsadmm_params &p = h->params;
     ControlParams cp{p.tau_incr, p.tau_decr, p.nu, p.eps_abs, p.eps_rel, h->nx, h->nmu, p.it_rho_limit, p.max_it};
     hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d_cb, sums_dev, cp, h->d_counters, trace_dev);
@@ -642,7 +698,7 @@ gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int3
                                  float *vertex_ms, int32_t *vertex_launches, float *edge_ms, int32_t *edge_launches)
 {
     if (!state_ok(h, st) || k < 0 || !vertex_ms || !edge_ms || !vertex_launches || !edge_launches) return GCSADMM_ERR_BAD_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    USE_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     const size_t need = (size_t)4 * k;
     while (h->events.size() < need) {
@@ -674,7 +730,7 @@ gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int3
 gcsadmm_status gcsadmm_read_control(gcsadmm_handle h, gcsadmm_control_block *out, void *stream)
 {
     if (!h || !out) return GCSADMM_ERR_BAD_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    USE_DEVICE(h);
     HIPCHK(h, hipMemcpyAsync(out, h->d_cb, sizeof(*out), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     return GCSADMM_OK;
@@ -683,7 +739,7 @@ gcsadmm_status gcsadmm_read_control(gcsadmm_handle h, gcsadmm_control_block *out
 gcsadmm_status gcsadmm_cost(gcsadmm_handle h, const gcsadmm_state *st, double eps_edge, double *cost_dev, void *stream)
 {
     if (!h || !st || !st->zv || !st->zedge || !cost_dev) return GCSADMM_ERR_BAD_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    USE_DEVICE(h);
     if (h->dtype == GCSADMM_F64)
         hipLaunchKernelGGL((cost_kernel<double>), dim3(1), dim3(256), 0, (hipStream_t)stream, h->V, h->E, h->n, st->zv,
                            (const double *)st->zedge, h->d_edge_counted, eps_edge, cost_dev);

@@ -76,6 +76,17 @@ __global__ __launch_bounds__(WAVE) void bounds_kernel(Polys S, const double *cen
 
 static std::string g_err;
 
+// the entry points switch to the requested device (upload_scene) and hand the caller's current device back on return
+struct RestoreDevice {
+    int prev = -1;
+    RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~RestoreDevice()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -173,6 +184,7 @@ const char *gcsadmm_polytope_last_error(void) { return g_err.c_str(); }
 int gcsadmm_polytope_centers(int n, int num_polytopes, const int *poly_ptr, const double *poly_A, const double *poly_b,
                              int device, double *centers, double *radii, int *status)
 {
+    RestoreDevice restore_device_;
     if (!centers) { g_err = "null output"; return GCSADMM_ERR_BAD_ARG; }
     Scene sc;
     int rc = upload_scene(sc, n, num_polytopes, poly_ptr, poly_A, poly_b, device);
@@ -198,6 +210,7 @@ int gcsadmm_polytope_centers(int n, int num_polytopes, const int *poly_ptr, cons
 int gcsadmm_polytope_bounds(int n, int num_polytopes, const int *poly_ptr, const double *poly_A, const double *poly_b,
                             const double *centers, int device, double *lo, double *hi, int *status)
 {
+    RestoreDevice restore_device_;
     if (!centers || !lo || !hi) { g_err = "null centres or output"; return GCSADMM_ERR_BAD_ARG; }
     Scene sc;
     int rc = upload_scene(sc, n, num_polytopes, poly_ptr, poly_A, poly_b, device);
@@ -220,6 +233,7 @@ int gcsadmm_polytope_overlaps(int n, int num_polytopes, const int *poly_ptr, con
                               const double *centers, long num_pairs, const int *pair_a, const int *pair_b, double tol,
                               int device, unsigned char *overlap, int *status)
 {
+    RestoreDevice restore_device_;
     if (num_pairs < 0 || (num_pairs > 0 && (!pair_a || !pair_b || !overlap))) { g_err = "null pair list or output"; return GCSADMM_ERR_BAD_ARG; }
     for (long t = 0; t < num_pairs; ++t)
         if (pair_a[t] < 0 || pair_a[t] >= num_polytopes || pair_b[t] < 0 || pair_b[t] >= num_polytopes) {

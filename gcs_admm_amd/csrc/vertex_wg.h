@@ -50,8 +50,13 @@ __device__ __forceinline__ int wg_tid()
     return t;
 }
 #define WG_FOR(i, cnt) for (int i = gcs_wg::wg_tid(), i##_end = (cnt); i < i##_end; i += gcs_wg::WG_THREADS)
+// the same with task 0 on thread `start`: a region with several KINDS of task starts each kind on its own wavefront
+// (Place, below); with every kind starting at thread 0 the first wavefront runs all kinds back to back while the others idle
+#define WG_FOR_AT(i, cnt, start) for (int i = (gcs_wg::wg_tid() - (start)) & (gcs_wg::WG_THREADS - 1), i##_end = (cnt); i < i##_end; i += gcs_wg::WG_THREADS)
 #define WG_SYNC() __syncthreads()
 #define WG_ONE() if (gcs_wg::wg_tid() == 0)
+// the serial cone algebra runs on the LAST thread: wave 3 has the fewest row / entry tasks in every region
+#define WG_CONE() if (gcs_wg::wg_tid() == gcs_wg::WG_THREADS - 1)
 #define WG_FENCE() asm volatile("" ::: "memory")
 #else
 #define WG_FENCE() do { } while (0)
@@ -61,8 +66,10 @@ __device__ __forceinline__ int wg_tid()
 #else
 #define WG_FOR(i, cnt) for (int i = 0, i##_end = (cnt); i < i##_end; ++i)
 #endif
+#define WG_FOR_AT(i, cnt, start) WG_FOR(i, ((void)(start), (cnt)))
 #define WG_SYNC() do { } while (0)
 #define WG_ONE() if (true)
+#define WG_CONE() if (true)
 #endif
 
 // diagnostic build (-DGCS_WG_TIMING, tools/wg_phase_timing.py): thread 0 of workgroup 0 accumulates the s_memtime ticks
@@ -88,6 +95,18 @@ __device__ __forceinline__ void wg_stamp(int id, unsigned long long &last)
 #define WG_STAMP_INIT() do { } while (0)
 #endif
 
+// first thread of each kind of task inside one region: kinds are laid out one after the other, each starting on a
+// wavefront boundary (wave-uniform arithmetic)
+struct Place {
+    int off = 0;
+    GCS_HD int at(int cnt)
+    {
+        const int start = off & (WG_THREADS - 1);
+        off = (off + cnt + 63) & ~63;
+        return start;
+    }
+};
+
 template <int N> struct WD {
     static constexpr int NW = 2 * N + 1, NX = 2 * N, NB1 = 4 * N + 1, Q = N + 1, NS = N * (N + 1) / 2;
     static constexpr int TA = 2 * NS + 2 * N + 1;   // Hessian assembly tasks per unit
@@ -109,16 +128,16 @@ template <int N> struct WL {
     static constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1;
     // fixed block
     static constexpr int CEN = 0, XV = CEN + pad2(N), DX = XV + pad2(NX), NU = DX + pad2(NX), DNU = NU + pad2(2 * NW),
-                         GBX = DNU + pad2(2 * NW), BS = GBX + pad2(NX), BSI = BS + pad2(2 * NW * NW), BXS = BSI + pad2(2 * NW * NW),
-                         PIVS = BXS + pad2(2 * NW * NX), BG = PIVS + pad2(2 * NW), XBG = BG + pad2(2 * NW), XBX = XBG + pad2(NX),
-                         RP = XBX + pad2(NX * NX), VV = RP + pad2(2 * NW), WW = VV + pad2(2 * NW), M = WW + pad2(2 * NW),
+                         BS = DNU + pad2(2 * NW), BSI = BS + pad2(2 * NW * NW), BXS = BSI + pad2(2 * NW * NW),
+                         PIVS = BXS + pad2(2 * NW * NX), BG = PIVS + pad2(2 * NW), XBG = BG + pad2(2 * NW), XBX = XBG + pad2(2 * NX),
+                         XS = XBX + pad2(2 * NX * NX), RP = XS + pad2(NX * N), VV = RP + pad2(2 * NW), WW = VV + pad2(2 * NW), M = WW + pad2(2 * NW),
                          MINV = M + pad2(NB1 * NB1), PIVM = MINV + pad2(NB1 * NB1), RHS = PIVM + pad2(NB1), SOL = RHS + pad2(NB1),
                          SOC = SOL + pad2(NB1), SC = SOC + pad2(WSoc<N>::SIZE), RED = SC + pad2(SC_N), FIXED = RED + 36;
-    // per-unit block (offsets from the unit's base); the four facet-row arrays (4m each) follow at ROWS
+    // per-unit block (offsets from the unit's base); the three facet-row arrays (4m each) follow at ROWS
     static constexpr int P = 0, DW = P + pad2(NW), TG = DW + pad2(NW), TF = TG + pad2(NW), LB = TF + pad2(N), KB = LB + 2, DLB = KB + 2,
-                         PIV = DLB + 2, G0 = PIV + pad2(NW), G = G0 + pad2(NW), GU = G + pad2(NW), GX = GU + pad2(NW), TE = GX + pad2(NX),
+                         PIV = DLB + 2, G0 = PIV + pad2(NW), GU = G0 + pad2(NW), GX = GU + pad2(NW), TE = GX + pad2(NX),
                          RV = TE + pad2(NW), K = RV + pad2(NW), X = K + pad2(NW * NW), B = X + pad2(NW * NX), ROWS = B + pad2(NW * NW);
-    static GCS_HD int unit_stride(int m) { return ROWS + 16 * m; }
+    static GCS_HD int unit_stride(int m) { return ROWS + 12 * m; }
     static GCS_HD int total(int U, int m) { return FIXED + U * unit_stride(m) + pad2(m * N) + pad2(m); }
 };
 template <int N> GCS_HD int wg_lds_doubles(int U, int m) { return WL<N>::total(U, m); }
@@ -195,40 +214,122 @@ GCS_HD Red3 wg_reduce(Red3 v, double *red, int &phase)
 #endif
 }
 
+// t = r (r + 1) / 2 + c with 0 <= c <= r  ->  (r, c), without a loop (exact for the sizes used here, t < 2^20)
+GCS_HD void tri_decode(int t, int &r, int &c)
+{
+    r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    if ((r + 1) * (r + 2) / 2 <= t) ++r;
+    if (r * (r + 1) / 2 > t) --r;
+    c = t - r * (r + 1) / 2;
+}
+
 // small-integer division by a run-time divisor without the ~40-instruction integer sequence (exact for the
 // ranges used here: dividend < 2^20, divisor <= 1024; the margin (0.5/div) dwarfs the float rounding)
 GCS_HD int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// cooperative Cholesky: `count` matrices of dimension `dim` (row-major, ld = dim, stride `mstride` between
-// matrices), lower triangle in place (strictly lower part = L, diagonal untouched), inverse pivots in piv.
-// Pivot rule of oracle chol(): a pivot that has cancelled below CHOL_SKIP of its diagonal entry is clamped there.
-// One parallel region per column; task = (matrix, row).
+// Cholesky of `count` SPD matrices of dimension DIM in LDS (row-major, ld = DIM, stride `mstride` between matrices):
+// lower triangle in place (strictly lower part = L, diagonal untouched), inverse pivots in piv (stride `pstride`).
+// Pivot rule of oracle chol(): a pivot that has cancelled below CHOL_SKIP of its ORIGINAL diagonal entry is clamped there.
+//
+// Tile-blocked, right-looking: the matrix is cut into tiles of at most 9 columns (5, 7, 9 -> one tile; 13 -> 6 + 7;
+// 25 -> 8 + 8 + 9).  Per tile: (1) ONE thread per matrix factors the diagonal tile in registers (packed lower, all
+// indices compile-time: ~TS^3/6 dependent FMAs, no LDS traffic inside); (2) one thread per row below solves its TS
+// entries against the tile (registers); (3) one thread per entry of the trailing matrix subtracts the tile's outer
+// product.  A column-at-a-time cooperative factorisation costs one barrier and ~1000 issue cycles PER COLUMN at these
+// sizes (measured, profiles/r02): the tiles keep the dependent chain in registers and need three barriers per tile.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DIM> GCS_HD void wg_chol(double *mats, double *piv, int count, int mstride, int pstride)
+GCS_HD constexpr int pki(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, i >= j
+
+template <int DIM, int T0, int TS>
+GCS_HD void wg_chol_tile(double *mats, double *piv, int count, int mstride, int pstride)
 {
-    for (int j = 0; j < DIM; ++j) {
-        WG_FOR(t, count * DIM) {
-            const int q = t / DIM, i = t - q * DIM;
-            if (i < j) continue;
-            double *Mq = mats + (size_t)q * mstride;
-            const double diag = Mq[j * DIM + j];
-            double dj = diag, s = Mq[i * DIM + j];
-            // all loads of the two row prefixes are issued unconditionally (one LDS round trip per step instead of one per
-            // term); terms beyond the prefix are masked out of the arithmetic
+    constexpr int REST = DIM - T0 - TS;
+    WG_FOR(q, count) {
+        double *Mq = mats + (size_t)q * mstride, *pq = piv + (size_t)q * pstride;
+        double a[TS * (TS + 1) / 2], od[TS];
 #pragma unroll
-            for (int k = 0; k < DIM - 1; ++k) {
-                const double lj = Mq[j * DIM + k], li = Mq[i * DIM + k];
-                const bool use = k < j;
-                dj -= use ? lj * lj : 0.0;
-                s -= use ? li * lj : 0.0;
-            }
-            if (!(dj > CHOL_SKIP * diag)) dj = diag > 0.0 ? CHOL_SKIP * diag : 1.0;
+        for (int i = 0; i < TS; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) a[pki(i, j)] = Mq[(T0 + i) * DIM + T0 + j];
+        if constexpr (T0 == 0) {
+            // original diagonal: of this tile from the registers; of the later tiles saved now, before the trailing
+            // updates change it
+#pragma unroll
+            for (int j = 0; j < TS; ++j) od[j] = a[pki(j, j)];
+#pragma unroll
+            for (int j = TS; j < DIM; ++j) pq[j] = Mq[j * DIM + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TS; ++j) od[j] = pq[T0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            double dj = a[pki(j, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) dj -= a[pki(j, k)] * a[pki(j, k)];
+            if (!(dj > CHOL_SKIP * od[j])) dj = od[j] > 0.0 ? CHOL_SKIP * od[j] : 1.0;
             const double inv = rsqrt_nr(dj);
-            if (i == j) piv[q * pstride + j] = inv;
-            else Mq[i * DIM + j] = s * inv;
+            pq[T0 + j] = inv;
+#pragma unroll
+            for (int i = j + 1; i < TS; ++i) {
+                double sij = a[pki(i, j)];
+#pragma unroll
+                for (int k = 0; k < j; ++k) sij -= a[pki(i, k)] * a[pki(j, k)];
+                a[pki(i, j)] = sij * inv;
+            }
+        }
+#pragma unroll
+        for (int i = 1; i < TS; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j) Mq[(T0 + i) * DIM + T0 + j] = a[pki(i, j)];
+    }
+    WG_SYNC();
+    if constexpr (REST > 0) {
+        WG_FOR(t, count * REST) {      // rows below the tile: L[i][tile] = A[i][tile] L_tile^{-T}
+            const int q = t / REST, i = T0 + TS + (t - q * REST);
+            double *Mq = mats + (size_t)q * mstride;
+            const double *pq = piv + (size_t)q * pstride;
+            double x[TS];
+#pragma unroll
+            for (int k = 0; k < TS; ++k) x[k] = Mq[i * DIM + T0 + k];
+#pragma unroll
+            for (int k = 0; k < TS; ++k) {
+                double sk = x[k];
+#pragma unroll
+                for (int pp = 0; pp < k; ++pp) sk -= x[pp] * Mq[(T0 + k) * DIM + T0 + pp];
+                x[k] = sk * pq[T0 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < TS; ++k) Mq[i * DIM + T0 + k] = x[k];
         }
         WG_SYNC();
+        WG_FOR(t, count * REST * REST) {   // trailing matrix (lower triangle): A[i][j] -= L[i][tile] . L[j][tile]
+            const int q = t / (REST * REST), rr = t - q * (REST * REST), ri = rr / REST, rj = rr - ri * REST;
+            if (ri < rj) continue;
+            double *Mq = mats + (size_t)q * mstride;
+            const int i = T0 + TS + ri, j = T0 + TS + rj;
+            double acc = 0;
+#pragma unroll
+            for (int k = 0; k < TS; ++k) acc += Mq[i * DIM + T0 + k] * Mq[j * DIM + T0 + k];
+            Mq[i * DIM + j] -= acc;
+        }
+        WG_SYNC();
+    }
+}
+
+template <int DIM> GCS_HD void wg_chol(double *mats, double *piv, int count, int mstride, int pstride)
+{
+    constexpr int NT = (DIM + 8) / 9, B1 = DIM / NT, B2 = 2 * DIM / NT;
+    static_assert(NT <= 3, "tile plan covers dimensions up to 27");
+    if constexpr (NT == 1) wg_chol_tile<DIM, 0, DIM>(mats, piv, count, mstride, pstride);
+    else if constexpr (NT == 2) {
+        wg_chol_tile<DIM, 0, B1>(mats, piv, count, mstride, pstride);
+        wg_chol_tile<DIM, B1, DIM - B1>(mats, piv, count, mstride, pstride);
+    } else {
+        wg_chol_tile<DIM, 0, B1>(mats, piv, count, mstride, pstride);
+        wg_chol_tile<DIM, B1, B2 - B1>(mats, piv, count, mstride, pstride);
+        wg_chol_tile<DIM, B2, DIM - B2>(mats, piv, count, mstride, pstride);
     }
 }
 
@@ -238,13 +339,14 @@ template <int DIM> GCS_HD void wg_chol(double *mats, double *piv, int count, int
 template <int DIM> GCS_HD void chol_inverse_col(const double *Lm, const double *piv, int c, double *out, int ldo)
 {
     double x[DIM];
+    // up to 9 x 9 the whole factor is read in one batch (45 values: one LDS round trip); larger ones row by row
 #pragma unroll
     for (int i = 0; i < DIM; ++i) {
         double s = (i == c) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= Lm[i * DIM + k] * x[k];
         x[i] = s * piv[i];
-        WG_FENCE();
+        if constexpr (DIM > 9) WG_FENCE();
     }
 #pragma unroll
     for (int i = DIM - 1; i >= 0; --i) {
@@ -252,37 +354,42 @@ template <int DIM> GCS_HD void chol_inverse_col(const double *Lm, const double *
 #pragma unroll
         for (int k = i + 1; k < DIM; ++k) s -= Lm[k * DIM + i] * x[k];
         x[i] = s * piv[i];
-        WG_FENCE();
+        if constexpr (DIM > 9) WG_FENCE();
     }
 #pragma unroll
     for (int i = 0; i < DIM; ++i) out[i * ldo + c] = x[i];
 }
 
-// the same with the column itself (in LDS) as the work vector, for dimensions whose register copy would spill: per row all
-// loads are issued unconditionally (one LDS round trip per row) and the terms outside the triangle are masked out
-template <int DIM> GCS_HD void chol_inverse_col_lds(const double *Lm, const double *piv, int c, double *out, int ldo)
+// Inverse of a larger SPD matrix from its factor in two parallel regions: (1) column c of L^{-1} by forward substitution
+// (one thread per column, the column in registers), written to `linv` (lower triangle, row-major ld = DIM); (2) every
+// entry of A^{-1} = L^{-T} L^{-1} as a dot product of two columns of L^{-1}, written as a full symmetric matrix over
+// the factor (`Lm`, dead by then).  Half the dependent chain of the column solves above, no register copy of DIM^2/2.
+template <int DIM> GCS_HD void wg_inverse_big(double *Lm, const double *piv, double *linv)
 {
-    for (int i = 0; i < c; ++i) out[i * ldo + c] = 0.0;
-    for (int i = c; i < DIM; ++i) {
-        double s = (i == c) ? 1.0 : 0.0;
+    WG_FOR(c, DIM) {
+        double x[DIM];
 #pragma unroll
-        for (int k = 0; k < DIM - 1; ++k) {
-            const double l = Lm[i * DIM + k], x = out[k * ldo + c];
-            s -= (k >= c && k < i) ? l * x : 0.0;
-        }
-        out[i * ldo + c] = s * piv[i];
-        WG_FENCE();
-    }
-    for (int i = DIM - 1; i >= 0; --i) {
-        double s = out[i * ldo + c];
+        for (int i = 0; i < DIM; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 1; k < DIM; ++k) {
-            const double l = Lm[k * DIM + i], x = out[k * ldo + c];
-            s -= k > i ? l * x : 0.0;
+            for (int k = 0; k < i; ++k) s -= Lm[i * DIM + k] * x[k];     // x[k] = 0 above the diagonal
+            x[i] = s * piv[i];
+            WG_FENCE();
         }
-        out[i * ldo + c] = s * piv[i];
-        WG_FENCE();
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) linv[i * DIM + c] = x[i];     // zeros above the diagonal
     }
+    WG_SYNC();
+    WG_FOR(t, DIM * DIM) {
+        const int i = t / DIM, j = t - i * DIM;
+        if (i < j) continue;
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) acc += linv[k * DIM + i] * linv[k * DIM + j];   // rows k < i hold zeros
+        Lm[i * DIM + j] = acc;
+        Lm[j * DIM + i] = acc;
+    }
+    WG_SYNC();
 }
 
 // Nesterov-Todd scaling of the cone from (s, z): wb (unit hyperbolic vector), eta; false on a boundary point
@@ -350,7 +457,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     const int US = W::unit_stride(m);
     const float inv_R = 1.0f / (float)R;
     auto UN = [&](int u) -> double * { return sm + W::FIXED + u * US; };       // base of unit u
-    const int oS = W::ROWS, oLAM = W::ROWS + R, oR1 = W::ROWS + 2 * R, oR2 = W::ROWS + 3 * R;   // facet-row arrays of a unit
+    const int oLAM = W::ROWS, oR1 = W::ROWS + R, oR2 = W::ROWS + 2 * R;   // facet-row arrays of a unit: duals, two work arrays
     double *const PA = sm + W::FIXED + U * US;
     const double *A = PA, *BC = PA + pad2(m * N), *CEN = sm + W::CEN;
     double *SOC = sm + W::SOC, *SC = sm + W::SC;
@@ -363,10 +470,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     auto side_hi = [&](int s) { return s ? d : d_in; };              // inclusive
 
     // ---- load: polytope, targets, start point (strictly feasible, as oracle_solve_vertex) ----
-    WG_FOR(t, m * N) PA[t] = a.poly_A[(size_t)p0 * N + t];
-    WG_FOR(j, m) PA[pad2(m * N) + j] = a.poly_bc[p0 + j];
-    WG_FOR(k, N) sm[W::CEN + k] = a.center[(size_t)v * N + k];
-    WG_FOR(t, d * NW) {
+    Place pl0;
+    WG_FOR_AT(t, d * NW, pl0.at(d * NW)) {
         const int e = t / NW, w = t - e * NW, inc = lo + e, edge = a.inc_edge[inc];
         double *un = UN(e + 1);
         const double Tw = (double)a.zedge[(size_t)w * a.E + edge] - mu_scale * (double)a.mu[(size_t)w * a.NI + inc];
@@ -377,7 +482,12 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         else if (w < N) { un[W::TF + w] = Tw; un[W::TG + N + w] = 0.0; }
         else un[W::TG + (w - N)] = Tw;
     }
-    WG_FOR(t, U * NW) {
+    WG_FOR_AT(t, m * N, pl0.at(m * N)) PA[t] = a.poly_A[(size_t)p0 * N + t];
+    WG_FOR_AT(j, m + N, pl0.at(m + N)) {
+        if (j < m) PA[pad2(m * N) + j] = a.poly_bc[p0 + j];
+        else sm[W::CEN + (j - m)] = a.center[(size_t)v * N + (j - m)];
+    }
+    WG_FOR_AT(t, U * NW, pl0.at(U * NW)) {
         const int u = t / NW, k = t - u * NW;
         double val = 0.0;
         if (k == 2 * N) val = u == 0 ? 0.5 : 0.5 / (double)(side_of(u) ? d_out : d_in);
@@ -401,6 +511,15 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         ty = rem >= m2; rem -= ty * m2;
         i = rem >= m; j = rem - i * m;
     };
+    // slack of a row at the current iterate (recomputed where needed: cheaper than 4m more doubles of LDS per unit, which
+    // is what decides how many workgroups a CU holds at n = 6): s_a = b y - a.p_i ; s_b = b (1 - y) - a.(x_i - p_i)
+    auto row_slack = [&](const double *un, int ty, int i, int j) {
+        double ap = 0, ax = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) { ap += A[j * N + k] * un[W::P + i * N + k]; ax += A[j * N + k] * sm[W::XV + i * N + k]; }
+        const double yy = un[W::P + 2 * N], b = BC[j];
+        return ty == 0 ? b * yy - ap : b * (1.0 - yy) - (ax - ap);
+    };
     // slack direction of a row for the direction (DW of its unit, DX): ds_a = b dy - a.dp_i ; ds_b = -b dy - a.(dx_i - dp_i)
     auto row_ds = [&](const double *un, int ty, int i, int j) {
         double adp = 0, adx = 0;
@@ -410,41 +529,55 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         return ty == 0 ? bdy - adp : -bdy - (adx - adp);
     };
 
-    // ---- Newton solve with the stored factors for the gradient (G of every unit, GBX, gt): -> DX, DW, DNU, dt (oracle newton_solve) ----
-    auto newton_solve = [&](int dt_slot) {
-        WG_FOR(t, d * NW) {      // t_e = B_e (-g_e)
+    // gradient entry k of unit u for the Newton right-hand side: smooth part G0, plus (corrector solve) G'kappa of the unit's
+    // facet rows and, on unit 0, the cone's kappa (-ks on z1, +ks on z2)
+    auto gval = [&](const double *un, int u, int k, bool wk) {
+        double g = un[W::G0 + k];
+        if (wk) {
+            g += un[W::GU + k];
+            if (u == 0 && k < 2 * N) g += k < N ? -SOC[SO::KS + 1 + k] : SOC[SO::KS + 1 + (k - N)];
+        }
+        return g;
+    };
+    // ---- Newton solve with the stored factors (oracle newton_solve): -> DX, DW of every unit, DNU, dt.  wk = corrector solve
+    //      (the gradient carries the kappa terms); the gradient of the t row is SC_GT.  The HEAD of a solve (four kinds of
+    //      task, one region each: t_e, their side sums, v_s, the right-hand side) does not need the border factor: for the
+    //      affine solve the four ride in the regions of the side / border factorisation (below), for the corrector they are
+    //      regions of their own (solve_head). ----
+    auto te_tasks = [&](Place &pl, bool wk) {      // t_e = B_e (-g_e)
+        WG_FOR_AT(t, d * NW, pl.at(d * NW)) {
             const int u = 1 + t / NW, i = t - (u - 1) * NW;
             double *un = UN(u);
             double s = 0;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) s -= un[W::B + i * NW + k] * un[W::G + k];
+            for (int k = 0; k < NW; ++k) s -= un[W::B + i * NW + k] * gval(un, u, k, wk);
             un[W::TE + i] = s;
         }
-        WG_SYNC();
-        WG_STAMP(30);
-        WG_FOR(t, 2 * NW + NX) {   // side sums of t_e; sum of X_e' t_e
-            if (t < 2 * NW) {
-                const int s = t / NW, i = t - s * NW;
-                double acc = 0;
+    };
+    auto bg_tasks = [&](Place &pl) {               // side sums of t_e; sum of X_e' t_e (the blocks in two halves)
+        WG_FOR_AT(t, 2 * NW, pl.at(2 * NW)) {
+            const int s = t / NW, i = t - s * NW;
+            double acc = 0;
 #pragma unroll 4
-                for (int u = side_lo(s); u <= side_hi(s); ++u) acc += UN(u)[W::TE + i];
-                sm[W::BG + t] = acc;
-            } else {
-                const int c = t - 2 * NW, h = c / N;
-                double acc = 0;
-#pragma unroll 2
-                for (int u = 1; u <= d; ++u) {
-                    const double *un = UN(u);
-#pragma unroll
-                    for (int k = 0; k < N; ++k) acc += un[W::X + (h * N + k) * NX + c] * un[W::TE + h * N + k];
-                    acc += un[W::X + 2 * N * NX + c] * un[W::TE + 2 * N];
-                }
-                sm[W::XBG + c] = acc;
-            }
+            for (int u = side_lo(s); u <= side_hi(s); ++u) acc += UN(u)[W::TE + i];
+            sm[W::BG + t] = acc;
         }
-        WG_SYNC();
-        WG_STAMP(31);
-        WG_FOR(t, 2 * NW) {      // v_s = Bs^{-1} (rp_s - Bg_s)
+        WG_FOR_AT(t, 2 * NX, pl.at(2 * NX)) {
+            const int part = t / NX, c = t - part * NX, h = c / N;
+            const int ulo = part ? 1 + d / 2 : 1, uhi = part ? d : d / 2;
+            double acc = 0;
+#pragma unroll 2
+            for (int u = ulo; u <= uhi; ++u) {
+                const double *un = UN(u);
+#pragma unroll
+                for (int k = 0; k < N; ++k) acc += un[W::X + (h * N + k) * NX + c] * un[W::TE + h * N + k];
+                acc += un[W::X + 2 * N * NX + c] * un[W::TE + 2 * N];
+            }
+            sm[W::XBG + t] = acc;
+        }
+    };
+    auto v_tasks = [&](Place &pl) {                // v_s = Bs^{-1} (rp_s - Bg_s)
+        WG_FOR_AT(t, 2 * NW, pl.at(2 * NW)) {
             const int s = t / NW, i = t - s * NW;
             const double *Bsi = sm + W::BSI + s * NW * NW;
             double acc = 0;
@@ -452,14 +585,18 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             for (int k = 0; k < NW; ++k) acc += Bsi[i * NW + k] * (sm[W::RP + s * NW + k] - sm[W::BG + s * NW + k]);
             sm[W::VV + t] = acc;
         }
-        WG_SYNC();
-        WG_STAMP(32);
-        WG_FOR(q, NB1) {         // right-hand side in the (x, u = z1 - z2, z2, y_v) variables, t eliminated
-            const double *g0 = UN(0) + W::G;
-            auto base_z = [&](int i) { return -g0[i] - sm[W::VV + i] - sm[W::VV + NW + i]; };
+    };
+    auto rhs_tasks = [&](Place &pl, bool wk) {     // right-hand side in the (x, u = z1 - z2, z2, y_v) variables, t eliminated
+        WG_FOR_AT(q, NB1, pl.at(NB1)) {
+            const double *u0 = UN(0);
+            auto base_z = [&](int i) { return -gval(u0, 0, i, wk) - sm[W::VV + i] - sm[W::VV + NW + i]; };
             double r;
             if (q < NX) {
-                r = -sm[W::GBX + q] - sm[W::XBG + q];
+                r = -REG_DELTA * sm[W::XV + q] - sm[W::XBG + q] - sm[W::XBG + NX + q];
+                if (wk) {
+#pragma unroll 4
+                    for (int u = 0; u <= d; ++u) r -= UN(u)[W::GX + q];
+                }
                 for (int s = 0; s < 2; ++s) {
                     const double *BXs = sm + W::BXS + s * NW * NX;
 #pragma unroll
@@ -474,10 +611,24 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             } else r = base_z(2 * N);
             sm[W::RHS + q] = r;
         }
+    };
+    auto solve_head = [&](bool wk) {
+        { Place pl; te_tasks(pl, wk); }
+        WG_SYNC();
+        WG_STAMP(30);
+        { Place pl; bg_tasks(pl); }
+        WG_SYNC();
+        WG_STAMP(31);
+        { Place pl; v_tasks(pl); }
+        WG_SYNC();
+        WG_STAMP(32);
+        { Place pl; rhs_tasks(pl, wk); }
         WG_SYNC();
         WG_STAMP(33);
+    };
+    auto solve_tail = [&](int dt_slot, bool wk) {
         WG_FOR(q, NB1) {
-            const double *Mi = sm + W::MINV + q * NB1;
+            const double *Mi = sm + (NB1 <= 13 ? W::MINV : W::M) + q * NB1;
             double acc = 0;
 #pragma unroll
             for (int p = 0; p < NB1; ++p) acc += Mi[p] * sm[W::RHS + p];
@@ -485,27 +636,26 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(34);
-        WG_FOR(t, NX + NW + 1) {  // back to (x, z1, z2, y_v), t recovered
-            double *u0 = UN(0);
+        // solution back in (x, z1, z2, y_v): dz1 = du + dz2
+        auto dzeta = [&](int i) { return i < N ? sm[W::SOL + NX + i] + sm[W::SOL + NX + N + i] : sm[W::SOL + NX + i]; };
+        Place plw;
+        WG_FOR_AT(t, 2 * NW, plw.at(2 * NW)) {     // w_s = d zeta + (rp_s - Bg_s) + BXs dx
+            const int s = t / NW, i = t - s * NW;
+            const double *BXs = sm + W::BXS + s * NW * NX;
+            double acc = dzeta(i) + (sm[W::RP + t] - sm[W::BG + t]);
+#pragma unroll
+            for (int c = 0; c < NX; ++c) acc += BXs[i * NX + c] * sm[W::SOL + c];
+            sm[W::WW + t] = acc;
+        }
+        WG_FOR_AT(t, NX + NW + 1, plw.at(NX + NW + 1)) {
             if (t < NX) sm[W::DX + t] = sm[W::SOL + t];
-            else if (t < NX + N) u0[W::DW + (t - NX)] = sm[W::SOL + t] + sm[W::SOL + t + N];     // dz1 = du + dz2
-            else if (t < NX + NW) u0[W::DW + (t - NX)] = sm[W::SOL + t];
-            else {
+            else if (t < NX + NW) UN(0)[W::DW + (t - NX)] = dzeta(t - NX);
+            else {                            // t recovered: c0 dt + cv'(dz1 - dz2) = -gt
                 double acc = -SC[SC_GT];
 #pragma unroll
                 for (int k = 0; k < N; ++k) acc -= SOC[SO::CV + k] * sm[W::SOL + NX + k];
                 SC[dt_slot] = acc * rcp(SC[SC_C0]);
             }
-        }
-        WG_SYNC();
-        WG_STAMP(35);
-        WG_FOR(t, 2 * NW) {      // w_s = d zeta + (rp_s - Bg_s) + BXs dx
-            const int s = t / NW, i = t - s * NW;
-            const double *BXs = sm + W::BXS + s * NW * NX;
-            double acc = UN(0)[W::DW + i] + (sm[W::RP + t] - sm[W::BG + t]);
-#pragma unroll
-            for (int c = 0; c < NX; ++c) acc += BXs[i * NX + c] * sm[W::DX + c];
-            sm[W::WW + t] = acc;
         }
         WG_SYNC();
         WG_STAMP(36);
@@ -522,7 +672,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_FOR(t, d * NW) {      // r_e = -g_e + d nu_side - X_e dx
             const int u = 1 + t / NW, i = t - (u - 1) * NW;
             double *un = UN(u);
-            double acc = -un[W::G + i] + sm[W::DNU + side_of(u) * NW + i];
+            double acc = -gval(un, u, i, wk) + sm[W::DNU + side_of(u) * NW + i];
             if (i < 2 * N) {
                 const int h = i / N;
 #pragma unroll
@@ -551,31 +701,54 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     for (it = 0;; ++it) {
         // ================= rows: slacks, duals at the start, D = l/s, complementarity =================
         double acc = 0.0; int bad = 0;
-        WG_FOR(r, RT) {
+        Place plr;
+        WG_FOR_AT(r, RT, plr.at(RT)) {
             int u, ro, ty, i, j;
             row_decode(r, u, ro, ty, i, j);
             double *un = UN(u);
-            double ap = 0, ax = 0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) { ap += A[j * N + k] * un[W::P + i * N + k]; ax += A[j * N + k] * sm[W::XV + i * N + k]; }
-            const double yy = un[W::P + 2 * N], b = BC[j];
-            const double s = ty == 0 ? b * yy - ap : b * (1.0 - yy) - (ax - ap);
+            const double s = row_slack(un, ty, i, j);
             const double is = rcp1(s);
             if (it == 0) un[oLAM + ro] = is;
             const double l = un[oLAM + ro];
-            un[oS + ro] = s;
             un[oR1 + ro] = l * is;
             acc += s * l;
             if (!(s > 0.0)) bad = 1;
         }
-        WG_FOR(u, U) {      // bounds 0 <= y <= 1 of every unit
+        WG_FOR_AT(u, U, plr.at(U)) {      // bounds 0 <= y <= 1 of every unit
             double *un = UN(u);
             const double yy = un[W::P + 2 * N], s5 = yy, s6 = 1.0 - yy;
             if (it == 0) { un[W::LB] = rcp1(s5); un[W::LB + 1] = rcp1(s6); }
             acc += s5 * un[W::LB] + s6 * un[W::LB + 1];
             if (!(s5 > 0.0) || !(s6 > 0.0)) bad = 1;
         }
-        WG_ONE() {          // the cone: s = (t, z1 - z2)
+        WG_FOR_AT(tg, U * NW, plr.at(U * NW)) {
+            // (rides in this region: it needs the primal iterate only)
+            // gradient of the smooth objective + equality multipliers + Tikhonov term (no facet-row part):
+            // blocks: consensus penalty (admm_solver_v3.py:392-413) and the edge cost 1e-4 y_e (:387-388)
+            const int u = tg / NW, k = tg - u * NW;
+            double *un = UN(u);
+            const double *p = un + W::P;
+            double g;
+            if (u == 0) g = sm[W::NU + k] + sm[W::NU + NW + k] + REG_DELTA * p[k];
+            else {
+                const bool out = side_of(u);
+                const double *tg_ = un + W::TG, *nu = sm + W::NU + (out ? NW : 0);
+                const double yy = p[2 * N];
+                if (k < N) g = rho * (p[k] + yy * CEN[k] - tg_[k]);
+                else if (k < 2 * N) g = out ? rho * (p[k] + yy * CEN[k - N] - tg_[k]) : 0.0;
+                else {
+                    g = rho * (yy - tg_[2 * N]) + a.eps_edge;
+#pragma unroll
+                    for (int c = 0; c < N; ++c) {
+                        g += CEN[c] * rho * (p[c] + yy * CEN[c] - tg_[c]);
+                        if (out) g += CEN[c] * rho * (p[N + c] + yy * CEN[c] - tg_[N + c]);
+                    }
+                }
+                g += REG_DELTA * p[k] - nu[k];
+            }
+            un[W::G0 + k] = g;
+        }
+        WG_CONE() {          // the cone: s = (t, z1 - z2)
             const double *u0 = UN(0);
             SOC[SO::SS] = SC[SC_T];
             for (int k = 0; k < N; ++k) SOC[SO::SS + 1 + k] = u0[W::P + k] - u0[W::P + N + k];
@@ -596,12 +769,15 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
 
         // ================= Hessian pieces of every unit, objective gradient, cone scaling =================
-        WG_FOR(t, 1 + U * TA + U * NW) {
-            if (t == 0) {
-                // cone scaling: W^{-2} = eta^{-2}(2 v v' - J), v = (wb0, -wb1); t is eliminated in closed form (c0, cv, Su):
-                // a numerical pivot on t cancels catastrophically once the cone is active
-                double wb[Q], eta = 1.0;
-                if (!soc_scaling_wb<Q>(SOC + SO::SS, SOC + SO::LS, wb, eta)) { SC[SC_CONEFAIL] = 1.0; continue; }
+        // K_u = [K1 0 k1y; 0 K2 k2y; . . kyy] (rows a+b), X_u = d(unit)/d(x) coupling (rows b); reference rows
+        // admm_solver_v3.py:420-426 (unit 0) and :434-440 (blocks).  Tasks are ordered BY KIND (all matrix entries, then all
+        // y-column entries, ...) so that the threads of a wavefront run the same loop: mixed kinds serialise per wavefront.
+        WG_CONE() {
+            // cone scaling: W^{-2} = eta^{-2}(2 v v' - J), v = (wb0, -wb1); t is eliminated in closed form (c0, cv, Su):
+            // a numerical pivot on t cancels catastrophically once the cone is active
+            double wb[Q], eta = 1.0;
+            if (!soc_scaling_wb<Q>(SOC + SO::SS, SOC + SO::LS, wb, eta)) SC[SC_CONEFAIL] = 1.0;
+            else {
                 SC[SC_CONEFAIL] = 0.0; SC[SC_ETA] = eta;
                 const double ieta = rcp(eta), ie2 = ieta * ieta;
 #pragma unroll
@@ -620,91 +796,67 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                     SOC[SO::CV + k] = -ie2 * 2.0 * wb[0] * wb[1 + k];
                     for (int l = 0; l < N; ++l) SOC[SO::SU + k * N + l] = ie2 * ((k == l ? 1.0 : 0.0) - g2 * wb[1 + k] * wb[1 + l]);
                 }
-                continue;
             }
-            const int ta = t - 1;
-            if (ta < U * TA) {
-                // K_u = [K1 0 k1y; 0 K2 k2y; . . kyy] (rows a+b), X_u = d(unit)/d(x) coupling (rows b); reference rows
-                // admm_solver_v3.py:420-426 (unit 0) and :434-440 (blocks)
-                const int u = ta / TA, q = ta - u * TA;
-                double *un = UN(u);
-                double *K = un + W::K, *X = un + W::X;
-                const double *Da = un + oR1, *Db = Da + m2;
-                const bool blk = u > 0, out = blk && side_of(u);
-                if (q < 2 * NS) {
-                    const int i = q / NS, pq = q - i * NS;
-                    int k = 0;
-                    while ((k + 1) * (k + 2) / 2 <= pq) ++k;
-                    const int l = pq - k * (k + 1) / 2;
-                    double sk = 0, sx = 0;
-#pragma unroll 4
-                    for (int j = 0; j < m; ++j) {
-                        const double aa = A[j * N + k] * A[j * N + l];
-                        sk += (Da[i * m + j] + Db[i * m + j]) * aa;
-                        sx += Db[i * m + j] * aa;
-                    }
-                    if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; }
-                    K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
-                    X[(i * N + k) * NX + i * N + l] = -sx; X[(i * N + l) * NX + i * N + k] = -sx;
-                    const int o = (1 - i) * N;      // the two halves are not coupled directly
-                    K[(i * N + k) * NW + o + l] = 0.0; K[(i * N + l) * NW + o + k] = 0.0;
-                    X[(i * N + k) * NX + o + l] = 0.0; X[(i * N + l) * NX + o + k] = 0.0;
-                } else if (q < 2 * NS + 2 * N) {
-                    const int ik = q - 2 * NS, i = ik / N, k = ik - i * N;
-                    double sk = 0, sx = 0;
-#pragma unroll 4
-                    for (int j = 0; j < m; ++j) {
-                        const double ba = BC[j] * A[j * N + k];
-                        sk -= (Da[i * m + j] + Db[i * m + j]) * ba;
-                        sx += Db[i * m + j] * ba;
-                    }
-                    if (blk && (i == 0 || out)) sk += rho * CEN[k];
-                    K[(i * N + k) * NW + 2 * N] = sk; K[2 * N * NW + i * N + k] = sk;
-                    X[2 * N * NX + i * N + k] = sx;
-                } else {
-                    double sk = 0;
-#pragma unroll 4
-                    for (int j = 0; j < m2; ++j) { const double b = BC[j >= m ? j - m : j]; sk += (Da[j] + Db[j]) * b * b; }
-                    const double yy = un[W::P + 2 * N];
-                    sk += un[W::LB] * rcp1(yy) + un[W::LB + 1] * rcp1(1.0 - yy) + REG_DELTA;
-                    if (blk) {
-                        double cc = 0;
-#pragma unroll
-                        for (int k = 0; k < N; ++k) cc += CEN[k] * CEN[k];
-                        sk += rho * (1.0 + (out ? 2.0 : 1.0) * cc);
-                    }
-                    K[2 * N * NW + 2 * N] = sk;
-                }
-            } else {
-                // gradient of the smooth objective + equality multipliers + Tikhonov term (no facet-row part):
-                // blocks: consensus penalty (admm_solver_v3.py:392-413) and the edge cost 1e-4 y_e (:387-388)
-                const int tg = ta - U * TA, u = tg / NW, k = tg - u * NW;
-                double *un = UN(u);
-                const double *p = un + W::P;
-                double g;
-                if (u == 0) g = sm[W::NU + k] + sm[W::NU + NW + k] + REG_DELTA * p[k];
-                else {
-                    const bool out = side_of(u);
-                    const double *tg_ = un + W::TG, *nu = sm + W::NU + (out ? NW : 0);
-                    const double yy = p[2 * N];
-                    if (k < N) g = rho * (p[k] + yy * CEN[k] - tg_[k]);
-                    else if (k < 2 * N) g = out ? rho * (p[k] + yy * CEN[k - N] - tg_[k]) : 0.0;
-                    else {
-                        g = rho * (yy - tg_[2 * N]) + a.eps_edge;
-#pragma unroll
-                        for (int c = 0; c < N; ++c) {
-                            g += CEN[c] * rho * (p[c] + yy * CEN[c] - tg_[c]);
-                            if (out) g += CEN[c] * rho * (p[N + c] + yy * CEN[c] - tg_[N + c]);
-                        }
-                    }
-                    g += REG_DELTA * p[k] - nu[k];
-                }
-                un[W::G0 + k] = g;
-                un[W::G + k] = g;
-            }
+            SC[SC_GT] = 1.0;
         }
-        WG_FOR(c, NX) sm[W::GBX + c] = REG_DELTA * sm[W::XV + c];
-        WG_ONE() SC[SC_GT] = 1.0;
+        // placement: K entries from thread 0, the K_yy tasks (longest loop) right behind them, the y-column tasks on the next
+        // wavefront boundary; the last wavefront is left to the cone thread where the task counts allow
+        const int nK_ = U * 2 * NS, sKyy_ = nK_ & (WG_THREADS - 1), sKy_ = ((nK_ + U + 63) & ~63) & (WG_THREADS - 1);
+        WG_FOR_AT(t, U * 2 * NS, 0) {          // entries of K_i and X_i (packed lower, both halves)
+            const int u = t / (2 * NS), q = t - u * (2 * NS), i = q / NS, pq = q - i * NS;
+            double *un = UN(u);
+            double *K = un + W::K, *X = un + W::X;
+            const double *Da = un + oR1, *Db = Da + m2;
+            const bool blk = u > 0, out = blk && side_of(u);
+            int k, l;
+            tri_decode(pq, k, l);
+            double sk = 0, sx = 0;
+#pragma unroll 4
+            for (int j = 0; j < m; ++j) {
+                const double aa = A[j * N + k] * A[j * N + l];
+                sk += (Da[i * m + j] + Db[i * m + j]) * aa;
+                sx += Db[i * m + j] * aa;
+            }
+            if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; }
+            K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
+            X[(i * N + k) * NX + i * N + l] = -sx; X[(i * N + l) * NX + i * N + k] = -sx;
+            const int o = (1 - i) * N;      // the two halves are not coupled directly
+            K[(i * N + k) * NW + o + l] = 0.0; K[(i * N + l) * NW + o + k] = 0.0;
+            X[(i * N + k) * NX + o + l] = 0.0; X[(i * N + l) * NX + o + k] = 0.0;
+        }
+        WG_FOR_AT(t, U * 2 * N, sKy_) {           // y column of K, y row of X
+            const int u = t / (2 * N), ik = t - u * (2 * N), i = ik / N, k = ik - i * N;
+            double *un = UN(u);
+            const double *Da = un + oR1, *Db = Da + m2;
+            const bool blk = u > 0, out = blk && side_of(u);
+            double sk = 0, sx = 0;
+#pragma unroll 4
+            for (int j = 0; j < m; ++j) {
+                const double ba = BC[j] * A[j * N + k];
+                sk -= (Da[i * m + j] + Db[i * m + j]) * ba;
+                sx += Db[i * m + j] * ba;
+            }
+            if (blk && (i == 0 || out)) sk += rho * CEN[k];
+            un[W::K + (i * N + k) * NW + 2 * N] = sk; un[W::K + 2 * N * NW + i * N + k] = sk;
+            un[W::X + 2 * N * NX + i * N + k] = sx;
+        }
+        WG_FOR_AT(u, U, sKyy_) {                   // K_yy
+            double *un = UN(u);
+            const double *Da = un + oR1, *Db = Da + m2;
+            const bool blk = u > 0, out = blk && side_of(u);
+            double sk = 0;
+#pragma unroll 4
+            for (int j = 0; j < m2; ++j) { const double b = BC[j >= m ? j - m : j]; sk += (Da[j] + Db[j]) * b * b; }
+            const double yy = un[W::P + 2 * N];
+            sk += un[W::LB] * rcp1(yy) + un[W::LB + 1] * rcp1(1.0 - yy) + REG_DELTA;
+            if (blk) {
+                double cc = 0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) cc += CEN[k] * CEN[k];
+                sk += rho * (1.0 + (out ? 2.0 : 1.0) * cc);
+            }
+            un[W::K + 2 * N * NW + 2 * N] = sk;
+        }
         WG_SYNC();
         WG_STAMP(2);
         if (SC[SC_CONEFAIL] != 0.0) { status = mu <= 1e3 * a.ipm_tol ? 0 : -4; break; }
@@ -719,7 +871,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(4);
-        WG_FOR(t, d * NW * NX) {     // B_e X_e, written over the (now dead) factor of the block
+        Place plx;
+        WG_FOR_AT(t, d * NW * NX, plx.at(d * NW * NX)) {     // B_e X_e, written over the (now dead) factor of the block
             const int u = 1 + t / (NW * NX), ic = t - (u - 1) * (NW * NX), i = ic / NX, c = ic - i * NX, h = c / N;
             double *un = UN(u);
             double s = un[W::B + i * NW + 2 * N] * un[W::X + 2 * N * NX + c];
@@ -727,41 +880,53 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             for (int k = 0; k < N; ++k) s += un[W::B + i * NW + h * N + k] * un[W::X + (h * N + k) * NX + c];
             un[W::K + ic] = s;
         }
+        te_tasks(plx, false);            // affine solve, head 1/4
         WG_SYNC();
         WG_STAMP(5);
         // ================= side sums: Bs, BXs, X'BX, equality residuals =================
-        WG_FOR(t, 2 * NW * NW + 2 * NW * NX + NX * NX + 2 * NW) {
-            if (t < 2 * NW * NW) {
-                const int s = t / (NW * NW), q = t - s * NW * NW;
-                double acc2 = 0;
+        Place plq;
+        WG_FOR_AT(t, 2 * NW * NW, plq.at(2 * NW * NW)) {
+            const int s = t / (NW * NW), q = t - s * NW * NW;
+            double acc2 = 0;
 #pragma unroll 4
-                for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::B + q];
-                sm[W::BS + t] = acc2;
-            } else if (t < 2 * NW * NW + 2 * NW * NX) {
-                const int tt = t - 2 * NW * NW, s = tt / (NW * NX), q = tt - s * NW * NX;
-                double acc2 = 0;
-#pragma unroll 4
-                for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::K + q];
-                sm[W::BXS + tt] = acc2;
-            } else if (t < 2 * NW * NW + 2 * NW * NX + NX * NX) {
-                const int tt = t - 2 * NW * NW - 2 * NW * NX, r = tt / NX, c = tt - r * NX, h = r / N;
-                double acc2 = 0;
-#pragma unroll 2
-                for (int u = 1; u <= d; ++u) {
-                    const double *un = UN(u);
-#pragma unroll
-                    for (int k = 0; k < N; ++k) acc2 += un[W::X + (h * N + k) * NX + r] * un[W::K + (h * N + k) * NX + c];
-                    acc2 += un[W::X + 2 * N * NX + r] * un[W::K + 2 * N * NX + c];
-                }
-                sm[W::XBX + tt] = acc2;
-            } else {
-                const int tt = t - 2 * NW * NW - 2 * NW * NX - NX * NX, s = tt / NW, k = tt - s * NW;
-                double acc2 = UN(0)[W::P + k];
-#pragma unroll 4
-                for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 -= UN(u)[W::P + k];
-                sm[W::RP + tt] = acc2;
-            }
+            for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::B + q];
+            sm[W::BS + t] = acc2;
         }
+        WG_FOR_AT(tt, 2 * NW * NX, plq.at(2 * NW * NX)) {
+            const int s = tt / (NW * NX), q = tt - s * NW * NX;
+            double acc2 = 0;
+#pragma unroll 4
+            for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::K + q];
+            sm[W::BXS + tt] = acc2;
+        }
+        WG_FOR_AT(tp, 2 * NX * NX, plq.at(2 * NX * NX)) {      // sum_e X_e' (B_e X_e), the blocks in two halves (shorter chains)
+            const int part = tp / (NX * NX), tt = tp - part * NX * NX, r = tt / NX, c = tt - r * NX, h = r / N;
+            const int ulo = part ? 1 + d / 2 : 1, uhi = part ? d : d / 2;
+            double acc2 = 0;
+#pragma unroll 2
+            for (int u = ulo; u <= uhi; ++u) {
+                const double *un = UN(u);
+#pragma unroll
+                for (int k = 0; k < N; ++k) acc2 += un[W::X + (h * N + k) * NX + r] * un[W::K + (h * N + k) * NX + c];
+                acc2 += un[W::X + 2 * N * NX + r] * un[W::K + 2 * N * NX + c];
+            }
+            sm[W::XBX + tp] = acc2;
+        }
+        WG_FOR_AT(tt, NX * N, plq.at(NX * N)) {                 // sum over ALL units of the x-x coupling (same half only)
+            const int r = tt / N, c = (r / N) * N + (tt - r * N);
+            double acc2 = 0;
+#pragma unroll 4
+            for (int u = 0; u <= d; ++u) acc2 += UN(u)[W::X + r * NX + c];
+            sm[W::XS + tt] = acc2;
+        }
+        WG_FOR_AT(tt, 2 * NW, plq.at(2 * NW)) {
+            const int s = tt / NW, k = tt - s * NW;
+            double acc2 = UN(0)[W::P + k];
+#pragma unroll 4
+            for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 -= UN(u)[W::P + k];
+            sm[W::RP + tt] = acc2;
+        }
+        bg_tasks(plq);                   // affine solve, head 2/4
         WG_SYNC();
         WG_STAMP(6);
         // ================= sides: factor, invert, Y_s = Bs^{-1} BXs (over the dead factor) =================
@@ -772,7 +937,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             chol_inverse_col<NW>(sm + W::BS + s * NW * NW, sm + W::PIVS + s * NW, c, sm + W::BSI + s * NW * NW, NW);
         }
         WG_SYNC();
-        WG_FOR(t, 2 * NW * NX) {
+        Place ply;
+        WG_FOR_AT(t, 2 * NW * NX, ply.at(2 * NW * NX)) {
             const int s = t / (NW * NX), ic = t - s * NW * NX, i = ic / NX, c = ic - i * NX;
             const double *Bsi = sm + W::BSI + s * NW * NW, *BXs = sm + W::BXS + s * NW * NX;
             double acc2 = 0;
@@ -780,42 +946,48 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             for (int k = 0; k < NW; ++k) acc2 += Bsi[i * NW + k] * BXs[k * NX + c];
             sm[W::BS + s * NW * NW + ic] = acc2;     // Y_s
         }
+        v_tasks(ply);                    // affine solve, head 3/4
         WG_SYNC();
         WG_STAMP(9);
         // ================= reduced border matrix in the (x, u, z2, y_v) variables =================
+        // step 1: every entry of the lower triangle in the (x, z1, z2, y_v) variables (into the MINV buffer, free until the
+        // inverse); step 2: the change of variables below needs up to four of them per entry
         {
             const double *YS0 = sm + W::BS, *YS1 = sm + W::BS + NW * NW, *u0 = UN(0);
-            // entry (r, c) of the matrix in the (x, z1, z2, y_v) variables
-            auto mval = [&](int r, int c) -> double {
-                if (r < c) { const int t_ = r; r = c; c = t_; }
-                if (r < NX) {                    // x-x
-                    double acc2 = (r == c ? REG_DELTA : 0.0) - sm[W::XBX + r * NX + c];
-                    if (r / N == c / N)
-#pragma unroll 4
-                        for (int u = 0; u <= d; ++u) acc2 -= UN(u)[W::X + r * NX + c];
+            double *MR = sm + W::MINV;
+            Place plm;
+            WG_FOR_AT(t, NX * (NX + 1) / 2, plm.at(NX * (NX + 1) / 2)) {        // x-x
+                int r, c;
+                tri_decode(t, r, c);
+                double val = (r == c ? REG_DELTA : 0.0) - sm[W::XBX + r * NX + c] - sm[W::XBX + NX * NX + r * NX + c];
+                if (r / N == c / N) val -= sm[W::XS + r * N + (c - (c / N) * N)];
 #pragma unroll
-                    for (int k = 0; k < NW; ++k)
-                        acc2 += sm[W::BXS + k * NX + r] * YS0[k * NX + c] + sm[W::BXS + NW * NX + k * NX + r] * YS1[k * NX + c];
-                    return acc2;
-                }
-                if (c < NX) {                    // zeta-x
-                    const int i = r - NX;
-                    return u0[W::X + i * NX + c] + YS0[i * NX + c] + YS1[i * NX + c];
-                }
-                const int i = r - NX, k = c - NX; // zeta-zeta
-                return u0[W::K + i * NW + k] + sm[W::BSI + i * NW + k] + sm[W::BSI + NW * NW + i * NW + k];
-            };
+                for (int k = 0; k < NW; ++k)
+                    val += sm[W::BXS + k * NX + r] * YS0[k * NX + c] + sm[W::BXS + NW * NX + k * NX + r] * YS1[k * NX + c];
+                MR[r * NB1 + c] = val;
+            }
+            WG_FOR_AT(t, NW * NX, plm.at(NW * NX)) {                            // zeta-x
+                const int i = t / NX, c = t - i * NX;
+                MR[(NX + i) * NB1 + c] = u0[W::X + i * NX + c] + YS0[i * NX + c] + YS1[i * NX + c];
+            }
+            WG_FOR_AT(t, NW * (NW + 1) / 2, plm.at(NW * (NW + 1) / 2)) {        // zeta-zeta
+                int i, k;
+                tri_decode(t, i, k);
+                MR[(NX + i) * NB1 + NX + k] = u0[W::K + i * NW + k] + sm[W::BSI + i * NW + k] + sm[W::BSI + NW * NW + i * NW + k];
+            }
+            rhs_tasks(plm, false);       // affine solve, head 4/4
+            WG_SYNC();
+            // change of variables (u, z2) = (z1 - z2, z2): columns / rows of z2 gain those of z1; the cone term Su then sits
+            // on u alone (with the cone inactive Su ~ 1/mu would cancel in the (z1, z2) form)
+            auto mr = [&](int r, int c) { return r >= c ? MR[r * NB1 + c] : MR[c * NB1 + r]; };
             WG_FOR(t, NB1 * (NB1 + 1) / 2) {
-                int r = 0;
-                while ((r + 1) * (r + 2) / 2 <= t) ++r;
-                const int c = t - r * (r + 1) / 2;
-                // change of variables (u, z2) = (z1 - z2, z2): columns/rows of z2 gain those of z1; the cone term Su then
-                // sits on u alone (with the cone inactive Su ~ 1/mu would cancel in the (z1, z2) form)
+                int r, c;
+                tri_decode(t, r, c);
                 const bool rz2 = r >= NX + N && r < NX + 2 * N, cz2 = c >= NX + N && c < NX + 2 * N;
-                double val = mval(r, c);
-                if (cz2) val += mval(r, c - N);
-                if (rz2) val += mval(r - N, c);
-                if (rz2 && cz2) val += mval(r - N, c - N);
+                double val = MR[r * NB1 + c];
+                if (cz2) val += mr(r, c - N);
+                if (rz2) val += mr(r - N, c);
+                if (rz2 && cz2) val += mr(r - N, c - N);
                 if (r >= NX && r < NX + N && c >= NX && c < NX + N) val += SOC[SO::SU + (r - NX) * N + (c - NX)];
                 sm[W::M + r * NB1 + c] = val;
             }
@@ -824,30 +996,29 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_STAMP(10);
         wg_chol<NB1>(sm + W::M, sm + W::PIVM, 1, NB1 * NB1, NB1);
         WG_STAMP(11);
-        WG_FOR(c, NB1) {
-            if constexpr (NB1 <= 13) chol_inverse_col<NB1>(sm + W::M, sm + W::PIVM, c, sm + W::MINV, NB1);
-            else chol_inverse_col_lds<NB1>(sm + W::M, sm + W::PIVM, c, sm + W::MINV, NB1);
-        }
-        WG_SYNC();
-
+        if constexpr (NB1 <= 13) {
+            WG_FOR(c, NB1) chol_inverse_col<NB1>(sm + W::M, sm + W::PIVM, c, sm + W::MINV, NB1);
+            WG_SYNC();
+        } else wg_inverse_big<NB1>(sm + W::M, sm + W::PIVM, sm + W::MINV);      // the inverse ends up in M
         WG_STAMP(12);
         // ================= affine direction (kappa = 0) =================
-        newton_solve(SC_DTA);
+        solve_tail(SC_DTA, false);      // the head of the affine solve rode in the factorisation regions above
         WG_STAMP(13);
         // rows: step bound, mu_aff sums, ds_a dl_a
         double rmax = 0.0, c1 = 0.0, c2 = 0.0;
-        WG_FOR(r, RT) {
+        Place plb;
+        WG_FOR_AT(r, RT, plb.at(RT)) {
             int u, ro, ty, i, j;
             row_decode(r, u, ro, ty, i, j);
             double *un = UN(u);
-            const double s = un[oS + ro], l = un[oLAM + ro], is = rcp1(s);
+            const double s = row_slack(un, ty, i, j), l = un[oLAM + ro], is = rcp1(s);
             const double ds = row_ds(un, ty, i, j);
             const double q = ds * is, dl = -l - l * q;          // dl / l = -1 - ds / s
             rmax = fmax(rmax, fmax(-q, 1.0 + q));
             c1 += s * dl + l * ds; c2 += ds * dl;
             un[oR1 + ro] = ds * dl;
         }
-        WG_FOR(u, U) {
+        WG_FOR_AT(u, U, plb.at(U)) {
             double *un = UN(u);
             const double yy = un[W::P + 2 * N], dy = un[W::DW + 2 * N];
             const double s5 = yy, s6 = 1.0 - yy, l5 = un[W::LB], l6 = un[W::LB + 1];
@@ -858,7 +1029,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             un[W::KB] = dy * dl5; un[W::KB + 1] = -dy * dl6;
         }
         double amax_cone = 1e300;
-        WG_ONE() {
+        WG_CONE() {
             const double *u0 = UN(0);
             SOC[SO::DSSA] = SC[SC_DTA];
             for (int k = 0; k < N; ++k) SOC[SO::DSSA + 1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
@@ -888,18 +1059,20 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             sigmu = sig * mu;
         }
         // ================= corrector: kappa = (sigma mu - ds_a dl_a) / s per row, cone part by thread 0 =================
-        WG_FOR(r, RT) {
-            const int u = fdiv(r, inv_R), ro = r - u * R;
+        Place plk;
+        WG_FOR_AT(r, RT, plk.at(RT)) {
+            int u, ro, ty, i, j;
+            row_decode(r, u, ro, ty, i, j);
             double *un = UN(u);
-            un[oR2 + ro] = (sigmu - un[oR1 + ro]) * rcp1(un[oS + ro]);
+            un[oR2 + ro] = (sigmu - un[oR1 + ro]) * rcp1(row_slack(un, ty, i, j));
         }
-        WG_FOR(u, U) {
+        WG_FOR_AT(u, U, plk.at(U)) {
             double *un = UN(u);
             const double yy = un[W::P + 2 * N];
             un[W::KB] = (sigmu - un[W::KB]) * rcp1(yy);
             un[W::KB + 1] = (sigmu - un[W::KB + 1]) * rcp1(1.0 - yy);
         }
-        WG_ONE() {   // kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) )
+        WG_CONE() {   // kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) )
             double wb[Q], a1[Q], a2[Q], pr[Q], qv[Q], xs[Q], lt[Q], ss[Q];
             const double eta = SC[SC_ETA];
 #pragma unroll
@@ -930,64 +1103,54 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(15);
-        // G' kappa per unit: own unknowns (GU) and the x part (GX)
-        WG_FOR(t, U * (NW + NX)) {
-            const int u = t / (NW + NX), q = t - u * (NW + NX);
+        // G' kappa per unit: own unknowns (GU) and the x part (GX); one loop per kind of task (uniform wavefronts)
+        Place plg;
+        WG_FOR_AT(t, U * 2 * N, plg.at(U * 2 * N)) {
+            const int u = t / (2 * N), q = t - u * (2 * N), i = q / N, k = q - i * N;
             double *un = UN(u);
             const double *ka = un + oR2, *kb = ka + m2;
             double s = 0;
-            if (q < 2 * N) {
-                const int i = q / N, k = q - i * N;
 #pragma unroll 4
-                for (int j = 0; j < m; ++j) s += A[j * N + k] * (ka[i * m + j] - kb[i * m + j]);
-                un[W::GU + q] = s;
-            } else if (q == 2 * N) {
+            for (int j = 0; j < m; ++j) s += A[j * N + k] * (ka[i * m + j] - kb[i * m + j]);
+            un[W::GU + q] = s;
+        }
+        WG_FOR_AT(t, U * NX, plg.at(U * NX)) {
+            const int u = t / NX, c = t - u * NX, i = c / N, k = c - i * N;
+            double *un = UN(u);
+            const double *kb = un + oR2 + m2;
+            double s = 0;
 #pragma unroll 4
-                for (int j = 0; j < m2; ++j) s += BC[j >= m ? j - m : j] * (kb[j] - ka[j]);
-                un[W::GU + q] = s - un[W::KB] + un[W::KB + 1];
-            } else {
-                const int c = q - NW, i = c / N, k = c - i * N;
+            for (int j = 0; j < m; ++j) s += A[j * N + k] * kb[i * m + j];
+            un[W::GX + c] = s;
+        }
+        WG_FOR_AT(u, U, plg.at(U)) {
+            double *un = UN(u);
+            const double *ka = un + oR2, *kb = ka + m2;
+            double s = 0;
 #pragma unroll 4
-                for (int j = 0; j < m; ++j) s += A[j * N + k] * kb[i * m + j];
-                un[W::GX + c] = s;
-            }
+            for (int j = 0; j < m2; ++j) s += BC[j >= m ? j - m : j] * (kb[j] - ka[j]);
+            un[W::GU + 2 * N] = s - un[W::KB] + un[W::KB + 1];
         }
         WG_SYNC();
         WG_STAMP(16);
-        WG_FOR(t, U * NW + NX) {
-            if (t < U * NW) {
-                const int u = t / NW, k = t - u * NW;
-                double *un = UN(u);
-                double g = un[W::G0 + k] + un[W::GU + k];
-                if (u == 0 && k < N) g -= SOC[SO::KS + 1 + k];
-                else if (u == 0 && k < 2 * N) g += SOC[SO::KS + 1 + (k - N)];
-                un[W::G + k] = g;
-            } else {
-                const int c = t - U * NW;
-                double g = REG_DELTA * sm[W::XV + c];
-#pragma unroll 4
-                for (int u = 0; u <= d; ++u) g += UN(u)[W::GX + c];
-                sm[W::GBX + c] = g;
-            }
-        }
-        WG_SYNC();
-        WG_STAMP(17);
-        newton_solve(SC_DT);
+        solve_head(true);
+        solve_tail(SC_DT, true);
         WG_STAMP(18);
         // ================= final direction: dual directions, step bound =================
         rmax = 0.0;
-        WG_FOR(r, RT) {
+        Place pld;
+        WG_FOR_AT(r, RT, pld.at(RT)) {
             int u, ro, ty, i, j;
             row_decode(r, u, ro, ty, i, j);
             double *un = UN(u);
-            const double s = un[oS + ro], l = un[oLAM + ro];
+            const double s = row_slack(un, ty, i, j), l = un[oLAM + ro];
             const double ip = rcp1(s * l), is = l * ip, il = s * ip;      // 1/s and 1/l from one reciprocal
             const double ds = row_ds(un, ty, i, j);
             const double dl = un[oR2 + ro] - l - (l * is) * ds;
             un[oR2 + ro] = dl;
             rmax = fmax(rmax, fmax(-ds * is, -dl * il));
         }
-        WG_FOR(u, U) {
+        WG_FOR_AT(u, U, pld.at(U)) {
             double *un = UN(u);
             const double yy = un[W::P + 2 * N], dy = un[W::DW + 2 * N];
             const double s5 = yy, s6 = 1.0 - yy, l5 = un[W::LB], l6 = un[W::LB + 1];
@@ -997,7 +1160,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             rmax = fmax(rmax, fmax(fmax(-dy * i5, -dl5 * rcp1(l5)), fmax(dy * i6, -dl6 * rcp1(l6))));
         }
         amax_cone = 1e300;
-        WG_ONE() {
+        WG_CONE() {
             const double *u0 = UN(0);
             SOC[SO::DSS] = SC[SC_DT];
             for (int k = 0; k < N; ++k) SOC[SO::DSS + 1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
@@ -1013,7 +1176,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         const Red3 rd = wg_reduce(Red3{fmin(rmax > 0.0 ? rcp1(rmax) : 1e300, amax_cone), 0.0, 0.0}, sm + W::RED, red_phase);
         WG_STAMP(19);
-        WG_ONE() {      // step length with the cone guard (round-off must not push either cone point outside)
+        WG_CONE() {      // step length with the cone guard (round-off must not push either cone point outside)
             double al = fmin(1.0, 0.99 * rd.mn);
             for (int tries = 0; tries < 40; ++tries) {
                 double s2[Q], l2[Q];
@@ -1029,23 +1192,26 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         const double alpha = SC[SC_ALPHA];
         stalled = alpha < 1e-3;
         // ================= update =================
-        WG_FOR(r, RT) {
+        Place plu;
+        WG_FOR_AT(r, RT, plu.at(RT)) {
             const int u = fdiv(r, inv_R), ro = r - u * R;
             double *un = UN(u);
             un[oLAM + ro] += alpha * un[oR2 + ro];
         }
-        WG_FOR(t, U * NW) {
+        WG_FOR_AT(t, U * NW, plu.at(U * NW)) {
             const int u = t / NW, k = t - u * NW;
             double *un = UN(u);
             un[W::P + k] += alpha * un[W::DW + k];
         }
-        WG_FOR(t, 2 * U) {
+        WG_FOR_AT(t, 2 * U, plu.at(2 * U)) {
             double *un = UN(t >> 1);
             un[W::LB + (t & 1)] += alpha * un[W::DLB + (t & 1)];
         }
-        WG_FOR(c, NX) sm[W::XV + c] += alpha * sm[W::DX + c];
-        WG_FOR(t, 2 * NW) sm[W::NU + t] += alpha * sm[W::DNU + t];
-        WG_ONE() {
+        WG_FOR_AT(t, NX + 2 * NW, plu.at(NX + 2 * NW)) {
+            if (t < NX) sm[W::XV + t] += alpha * sm[W::DX + t];
+            else sm[W::NU + (t - NX)] += alpha * sm[W::DNU + (t - NX)];
+        }
+        WG_CONE() {
             SC[SC_T] += alpha * SC[SC_DT];
             for (int k = 0; k < Q; ++k) SOC[SO::LS + k] += alpha * SOC[SO::DLS + k];
         }
@@ -1058,7 +1224,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     WG_SYNC();
     if (status != 0) return;      // inner failure: the previous copy columns stay (admm_solver_v3.py:524-538 intent)
     // ---- un-centre and write out ----
-    WG_FOR(t, d * NW) {
+    Place plo;
+    WG_FOR_AT(t, d * NW, plo.at(d * NW)) {
         const int e = t / NW, w = t - e * NW, inc = lo + e;
         const bool out = e >= d_in;
         const double *un = UN(e + 1), *p = un + W::P;
@@ -1069,7 +1236,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         else val = out ? p[w] + yy * CEN[w - N] : p[w - N] + yy * CEN[w - N];
         a.copy[(size_t)w * a.NI + inc] = (T)val;
     }
-    WG_FOR(k, NX) {
+    WG_FOR_AT(k, NX, plo.at(NX)) {
         const int c = k < N ? k : k - N;
         const double *u0 = UN(0);
         a.xv[(size_t)v * NX + k] = sm[W::XV + k] + CEN[c];

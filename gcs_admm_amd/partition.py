@@ -14,7 +14,7 @@ Everything here is plain index bookkeeping on the host (numpy); the exchange its
 from __future__ import annotations
 
 import dataclasses
-from typing import Dict, List
+from typing import Dict
 
 import numpy as np
 
@@ -27,14 +27,16 @@ def strip_owner(g: GcsGraph, world: int) -> np.ndarray:
     neighbours' rank (first / last strip)."""
     V = g.num_vertices
     deg = np.diff(g.inc_ptr).astype(np.int64) + 1
-    others = np.array([v for v in range(V) if v not in (g.src, g.dst)], dtype=np.int64)
+    mask = np.ones(V, bool); mask[[g.src, g.dst]] = False
+    others = np.nonzero(mask)[0]
     cum = np.cumsum(deg[others])
     owner = np.zeros(V, dtype=np.int32)
     bounds = cum[-1] * (np.arange(1, world) / world) if len(cum) else np.zeros(0)
     owner[others] = np.searchsorted(bounds, cum - deg[others] / 2.0, side="right")
     for term in (g.src, g.dst):
-        nb = [g.edge_head[e] for e in range(g.num_edges) if g.edge_tail[e] == term] or [others[0] if len(others) else 0]
-        owner[term] = owner[nb[0]] if nb[0] not in (g.src, g.dst) else 0
+        nb = g.edge_head[g.edge_tail == term]
+        first = int(nb[0]) if len(nb) else (int(others[0]) if len(others) else 0)
+        owner[term] = owner[first] if first not in (g.src, g.dst) else 0
     return owner
 
 
@@ -54,71 +56,73 @@ class LocalPartition:
     recv_idx: Dict[int, np.ndarray]  # neighbour rank -> ghost columns to fill (same canonical order)
 
 
+def _ranges(starts: np.ndarray, counts: np.ndarray) -> np.ndarray:
+    """concatenation of arange(starts[i], starts[i] + counts[i])"""
+    tot = int(counts.sum())
+    if tot == 0:
+        return np.zeros(0, np.int64)
+    rep = np.repeat(starts - np.concatenate([[0], np.cumsum(counts)[:-1]]), counts)
+    return rep + np.arange(tot)
+
+
 def build_partition(g: GcsGraph, owner: np.ndarray, rank: int, world: int) -> LocalPartition:
+    """Rank ``rank``'s part of the graph: its vertices (global order), every edge touching them, one ghost copy column per
+    cut edge, ownership masks and the halo index lists.  Pure index arithmetic (numpy, no Python loop over vertices or
+    edges): 100k vertices / 400k edges take well under a second per rank."""
     V, E, n = g.num_vertices, g.num_edges, g.n
+    owner = np.asarray(owner)
     mine_v = np.nonzero(owner == rank)[0]
     vloc = -np.ones(V, dtype=np.int64); vloc[mine_v] = np.arange(len(mine_v))
     t_own, h_own = owner[g.edge_tail], owner[g.edge_head]
     mine_e = np.nonzero((t_own == rank) | (h_own == rank))[0]
     eloc = -np.ones(E, dtype=np.int64); eloc[mine_e] = np.arange(len(mine_e))
     # local CSR over owned vertices (same incidence order as the global graph)
-    inc_ptr = np.zeros(len(mine_v) + 1, dtype=np.int64)
-    inc_edge, inc_out = [], []
-    col_of = {}                                      # (global edge, is_head) -> local column
-    for lv, v in enumerate(mine_v):
-        lo, hi = g.inc_ptr[v], g.inc_ptr[v + 1]
-        for k in range(lo, hi):
-            e = g.inc_edge[k]
-            col_of[(int(e), int(not g.inc_out[k]))] = len(inc_edge)
-            inc_edge.append(eloc[e]); inc_out.append(g.inc_out[k])
-        inc_ptr[lv + 1] = len(inc_edge)
-    ni_owned = len(inc_edge)
+    gptr = g.inc_ptr.astype(np.int64)
+    degs = gptr[mine_v + 1] - gptr[mine_v]
+    inc_idx = _ranges(gptr[mine_v], degs)                      # global incidence slots of the owned vertices, in order
+    inc_ptr = np.zeros(len(mine_v) + 1, dtype=np.int64); inc_ptr[1:] = np.cumsum(degs)
+    inc_edge_g = g.inc_edge[inc_idx].astype(np.int64)
+    inc_out = g.inc_out[inc_idx].astype(np.int32)
+    ni_owned = len(inc_idx)
+    # column of (global edge, side): side 0 = the tail's copy, 1 = the head's copy
+    col = -np.ones(2 * E, dtype=np.int64)
+    col[2 * inc_edge_g + (1 - inc_out)] = np.arange(ni_owned)
     # ghost columns: the remote endpoint's copy of each cut edge, ordered by (global edge, side)
-    ghosts = []
-    for e in mine_e:
-        if t_own[e] != rank:
-            ghosts.append((int(e), 0, int(t_own[e])))
-        if h_own[e] != rank:
-            ghosts.append((int(e), 1, int(h_own[e])))
-    for i, (e, side, _r) in enumerate(ghosts):
-        col_of[(e, side)] = ni_owned + i
-    ni = ni_owned + len(ghosts)
-    edge_inc_tail = np.array([col_of[(int(e), 0)] for e in mine_e], dtype=np.int32)
-    edge_inc_head = np.array([col_of[(int(e), 1)] for e in mine_e], dtype=np.int32)
+    side_owner = np.stack([t_own[mine_e], h_own[mine_e]], 1).ravel()          # [(e, side)] in (edge, side) order
+    side_key = (2 * mine_e[:, None] + np.arange(2)[None, :]).ravel()
+    ghost = side_owner != rank
+    col[side_key[ghost]] = ni_owned + np.arange(int(ghost.sum()))
+    ni = ni_owned + int(ghost.sum())
+    edge_inc_tail = col[2 * mine_e].astype(np.int32)
+    edge_inc_head = col[2 * mine_e + 1].astype(np.int32)
     inc_counted = np.zeros(ni, dtype=np.uint8); inc_counted[:ni_owned] = 1
     edge_counted = (t_own[mine_e] == rank).astype(np.uint8)
     # halo lists: with neighbour r, for every cut edge between us in (global edge, side) order, the side
     # that is MINE is sent and the side that is THEIRS is received
-    send: Dict[int, List[int]] = {}
-    recv: Dict[int, List[int]] = {}
-    for e in mine_e:
-        for side, own in ((0, t_own[e]), (1, h_own[e])):
-            other = h_own[e] if side == 0 else t_own[e]
-            if own == rank and other != rank:
-                send.setdefault(int(other), []).append(col_of[(int(e), side)])
-            elif own != rank:
-                recv.setdefault(int(own), []).append(col_of[(int(e), side)])
-    poly_ptr = np.zeros(len(mine_v) + 1, dtype=np.int64)
-    As, bs = [], []
-    for lv, v in enumerate(mine_v):
-        As.append(g.poly_A[g.poly_ptr[v]:g.poly_ptr[v + 1]]); bs.append(g.poly_b[g.poly_ptr[v]:g.poly_ptr[v + 1]])
-        poly_ptr[lv + 1] = poly_ptr[lv] + len(bs[-1])
+    other_owner = np.stack([h_own[mine_e], t_own[mine_e]], 1).ravel()          # owner of the opposite endpoint
+    send_mask = (side_owner == rank) & (other_owner != rank)
+    send = {int(r): col[side_key[send_mask & (other_owner == r)]] for r in np.unique(other_owner[send_mask])}
+    recv = {int(r): col[side_key[ghost & (side_owner == r)]] for r in np.unique(side_owner[ghost])}
+    pptr = g.poly_ptr.astype(np.int64)
+    ms = pptr[mine_v + 1] - pptr[mine_v]
+    rows = _ranges(pptr[mine_v], ms)
+    poly_ptr = np.zeros(len(mine_v) + 1, dtype=np.int64); poly_ptr[1:] = np.cumsum(ms)
     local = GcsGraph(
         n=n, keys=[g.keys[v] for v in mine_v],
-        edge_tail=np.array([vloc[g.edge_tail[e]] for e in mine_e], dtype=np.int32),    # -1 = remote vertex
-        edge_head=np.array([vloc[g.edge_head[e]] for e in mine_e], dtype=np.int32),
-        inc_ptr=inc_ptr.astype(np.int32), inc_edge=np.array(inc_edge, dtype=np.int32),
-        inc_out=np.array(inc_out, dtype=np.int32), edge_inc_tail=edge_inc_tail, edge_inc_head=edge_inc_head,
+        edge_tail=vloc[g.edge_tail[mine_e]].astype(np.int32),    # -1 = remote vertex
+        edge_head=vloc[g.edge_head[mine_e]].astype(np.int32),
+        inc_ptr=inc_ptr.astype(np.int32), inc_edge=eloc[inc_edge_g].astype(np.int32),
+        inc_out=inc_out, edge_inc_tail=edge_inc_tail, edge_inc_head=edge_inc_head,
         poly_ptr=poly_ptr.astype(np.int32),
-        poly_A=np.ascontiguousarray(np.vstack(As)) if As else np.zeros((0, n)),
-        poly_b=np.ascontiguousarray(np.hstack(bs)) if bs else np.zeros(0),
+        poly_A=np.ascontiguousarray(g.poly_A[rows]).reshape(-1, n),
+        poly_b=np.ascontiguousarray(g.poly_b[rows]),
         interior=np.ascontiguousarray(g.interior[mine_v]),
         src=int(vloc[g.src]), dst=int(vloc[g.dst]))
     return LocalPartition(rank=rank, world=world, graph=local, num_incidences=ni, inc_counted=inc_counted,
                           edge_counted=edge_counted, nx_global=float(g.nx), nmu_global=float(g.nmu),
                           vertex_global=mine_v, edge_global=mine_e,
-                          send_idx={r: np.array(v, dtype=np.int64) for r, v in send.items()},
-                          recv_idx={r: np.array(v, dtype=np.int64) for r, v in recv.items()})
+                          send_idx={r: np.asarray(v, dtype=np.int64) for r, v in send.items()},
+                          recv_idx={r: np.asarray(v, dtype=np.int64) for r, v in recv.items()})
 
 
 class PartitionedLoop:

@@ -12,8 +12,9 @@ few hundred regions.  Here:
      decision as the reference's feasibility solve (closed sets, touching counts);
   4. edges in the reference's double-loop order, both directions of every intersecting pair.
 
-There is no host fallback in this module: it raises if the HIP library or a device is missing.  The host
-functions of ``gcs_admm_amd.graph`` (scipy LPs) remain what the small reference cases are built with.
+It raises if the HIP library or a device is missing.  LP statuses are checked (build_graph_device): the only host LPs this
+module ever runs are re-decisions of overlap LPs that hit their iteration limit.  The host functions of
+``gcs_admm_amd.graph`` (scipy LPs) remain what the small reference cases are built with.
 """
 from __future__ import annotations
 
@@ -107,18 +108,47 @@ def candidate_pairs(lo: np.ndarray, hi: np.ndarray, pad: float = 1e-7):
     return a, b
 
 
-def build_graph_device(As: Dict[Hashable, np.ndarray], bs: Dict[Hashable, np.ndarray], device: int = 0, tol: float = 1e-9):
+def build_graph_device(As: Dict[Hashable, np.ndarray], bs: Dict[Hashable, np.ndarray], device: int = 0, tol: float = 1e-9,
+                       scene=None, stats: dict | None = None):
     """``utils.build_graph`` (reference utils.py:31-82) with the LPs on the device.  Returns
-    ``(vertices, edges, I_v_in, I_v_out, centres)``; ``edges`` in the reference's double-loop order."""
+    ``(vertices, edges, I_v_in, I_v_out, centres)``; ``edges`` in the reference's double-loop order.
+
+    Every LP reports a status (0 converged, 1 / 2 decided early, -1 iteration limit) and none is ignored:
+      * a centre LP that did not converge has no trustworthy interior point -> GcsAdmmError naming the regions;
+      * a bounding-box LP that did not converge returns an INTERIOR iterate, i.e. a box that is too small, and the sweep
+        would silently drop real neighbours: that side of the box is opened up (+-inf), which only adds candidates;
+      * an overlap LP that did not converge is decided again by the host LP of ``graph.polytopes_overlap`` (one HiGHS
+        solve per pair, the reference's own method) instead of from its unfinished iterate.
+    ``stats`` (optional dict) receives the counts.  ``scene``: a prepared PolytopeScene (tests inject one)."""
     vertices = list(As.keys())
-    scene = PolytopeScene([(As[v], bs[v]) for v in vertices], device)
-    cen, rad, _ = scene.centers()
+    if scene is None:
+        scene = PolytopeScene([(As[v], bs[v]) for v in vertices], device)
+    cen, rad, st_c = scene.centers()
+    if np.any(st_c < 0):
+        bad = [vertices[i] for i in np.nonzero(st_c < 0)[0][:8]]
+        raise GcsAdmmError(f"centre LP did not converge for regions {bad} (of {int((st_c < 0).sum())})")
     if np.any(rad <= 0):
         bad = [vertices[i] for i in np.nonzero(rad <= 0)[0][:5]]
         raise ValueError(f"regions without interior: {bad}")
-    lo, hi, _ = scene.bounds(cen)
+    lo, hi, st_b = scene.bounds(cen)
+    n = lo.shape[1]
+    # status layout of gcsadmm_polytope_bounds (polytope_lp.hip bounds_kernel): [P][n][2] = (min, max) per axis
+    st_b = np.asarray(st_b).reshape(len(vertices), n, 2)
+    fail_lo, fail_hi = st_b[:, :, 0] < 0, st_b[:, :, 1] < 0
+    lo = np.where(fail_lo, -np.inf, lo); hi = np.where(fail_hi, np.inf, hi)
     pa, pb = candidate_pairs(lo, hi)
-    flags, _ = scene.overlaps(pa, pb, tol, cen)
+    flags, st_o = scene.overlaps(pa, pb, tol, cen)
+    redo = np.nonzero(np.asarray(st_o) < 0)[0]
+    if len(redo):
+        from .graph import polytopes_overlap
+        flags = np.array(flags, copy=True)
+        for t in redo:
+            u, w = vertices[pa[t]], vertices[pb[t]]
+            flags[t] = 1 if polytopes_overlap(np.asarray(As[u], float), np.asarray(bs[u], float),
+                                              np.asarray(As[w], float), np.asarray(bs[w], float)) else 0
+    if stats is not None:
+        stats.update(bounds_opened=int(fail_lo.sum() + fail_hi.sum()), overlaps_redone_on_host=int(len(redo)),
+                     candidate_pairs=int(len(pa)))
     a = pa[flags != 0]; b = pb[flags != 0]
     tail = np.concatenate([a, b]); head = np.concatenate([b, a])
     o = np.lexsort((head, tail))                      # double-loop order: by tail, then head

@@ -225,21 +225,35 @@ class DeviceSolver:
         return float(self._cost.item())
 
     # ------------------------------------------------------------------
-    def solve(self, chunk: int = 25, **params):
+    def solve(self, chunk: int = 25, timed: bool = False, **params):
         """Run the loop to its stop test (or max_it), polling the device control
         block every ``chunk`` iterations; returns the reference's record fields
-        (utils.py:212-229 naming) plus solver statistics."""
+        (utils.py:212-229 naming) plus solver statistics.
+
+        ``timed``: bracket every kernel launch with HIP events (gcsadmm_run_timed) and report ``device_time_s``, the
+        summed device time of the vertex-step and edge-step kernels -- the counterpart of the reference's
+        ``solve_time``, which adds up SolveInParallel and the edge loop only (admm_solver_v3.py:489-491, 579-585,
+        660, 677).  ``wall_time_s`` is the host wall time of the loop either way."""
+        import time
         self.reset(**params)
         max_it = self.params.max_it
         done = 0
+        dev_ms = 0.0
+        self.torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
         while True:
             k = min(chunk, max_it - done)
             if k > 0:
-                self.enqueue(k)
+                if timed:
+                    tm = self.enqueue_timed(k)
+                    dev_ms += tm["vertex_ms"] + tm["edge_ms"]
+                else:
+                    self.enqueue(k)
                 done += k
             cb = self.read_control()
             if cb.status != RUNNING or done >= max_it:
                 break
+        wall = time.perf_counter() - t0
         it = cb.it
         k = min(it, max_it)
         tr = self.trace[:k].cpu().numpy()
@@ -248,4 +262,5 @@ class DeviceSolver:
                     pri_res_seq=np.concatenate([[0.0], tr[:, 1]]),
                     dual_res_seq=np.concatenate([[0.0], tr[:, 2]]),
                     eps_pri_seq=tr[:, 3], eps_dual_seq=tr[:, 4],
-                    inner_failures=int(tr[:, 5].sum()), cost=self.cost())
+                    inner_failures=int(tr[:, 5].sum()), cost=self.cost(),
+                    wall_time_s=wall, device_time_s=(dev_ms * 1e-3 if timed else None))

@@ -1,5 +1,5 @@
 """Case module in the reference's contract (``As``, ``bs`` dicts keyed 's', 't', 0..K-1; ``n``; ``N``, ``M``),
-numeric content from the committed fixture tests/golden/benchmark4.json."""
+numeric content in test_data/benchmark4.json."""
 from gcs_admm_amd.cases import fixture_sets
 
 As, bs, n, N, M = fixture_sets("benchmark4")

@@ -61,6 +61,9 @@ def main():
             "edges": [[_key(u), _key(w)] for u, w in E],
             "N": int(getattr(mod, "N", 0)), "M": int(getattr(mod, "M", 0)),
         }
+        # the case content alone (no reference results) also ships with the product: test_data/<case>.json
+        with open(os.path.join(ROOT, "test_data", f"{case}.json"), "w") as f:
+            json.dump(rec, f)
         pk = os.path.join(REF, "benchmark_data", f"admm_solver_v3_{case}.pkl")
         if os.path.exists(pk):
             d = load_data(pk)

@@ -1,0 +1,219 @@
+"""GPU tests of the BASELINE.json configurations at their FULL sizes (the parity tests of test_gpu_parity.py use the
+reference's own cases and small lattices):
+
+  config 2  benchmark4, f64, tolerance 1e-6 (iterations-to-eps run)            test_benchmark4_tol_1e6_against_oracle
+  config 3  10k-vertex lattice, f32 state, reference defaults to its stop      test_lattice_10k_f32_runs_to_the_same_stop
+  config 4  100k-vertex lattice (316 x 317), one handle and 8 partitions       test_lattice_100k_*
+  config 5  50k-vertex lattice in R^6 (223 x 224)                             test_lattice_r6_50k
+
+Where the oracle can afford the size it is run beside the device (same inner solver, tight tolerances); everything else
+is checked through properties that need no second implementation: the five norms recomputed with torch from the state
+the kernels left behind, the mu-pair invariant, activations in [0, 1], s / t switched on, no inner failure.
+Reference loop: admm_solver_v3.py:655-733."""
+import numpy as np
+import pytest
+
+from gcs_admm_amd.cases import load_fixture
+from gcs_admm_amd.graph import lattice_boxes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _solver(g, dtype="f64", **kw):
+    from gcs_admm_amd.solver import DeviceSolver
+    return DeviceSolver(g, dtype, device=0, **kw)
+
+
+def _check_state_properties(torch, g, d, sums, dtype):
+    """the five norms recomputed from the state, mu-pair invariant, activations in [0, 1], terminals on"""
+    n = g.n
+    tail = torch.from_numpy(g.edge_inc_tail.astype(np.int64)).cuda()
+    head = torch.from_numpy(g.edge_inc_head.astype(np.int64)).cuda()
+    copy = d.copy.double(); z = d.zedge.double(); mu = d.mu.double()
+    assert torch.isfinite(copy).all()
+    r = torch.cat([copy[:, tail] - z, copy[:, head] - z], 1)
+    assert torch.allclose(sums[0], (r * r).sum(), rtol=1e-9 if dtype == "f64" else 1e-4)
+    assert torch.allclose(sums[2], (copy * copy).sum(), rtol=1e-9)
+    assert torch.allclose(sums[3], (z * z).sum(), rtol=1e-9)
+    assert torch.allclose(sums[4], (mu * mu).sum(), rtol=1e-9)
+    # the two duals of a coupled word cancel: exactly in f64 arithmetic up to round-off, to storage precision (a few f32
+    # ulps of the largest dual: the 100k lattice has coordinates ~300) with f32 state
+    pair_tol = 1e-12 if dtype == "f64" else 5e-7 * max(1.0, mu.abs().max().item())
+    assert (mu[:, tail] + mu[:, head]).abs().max().item() <= pair_tol
+    assert z[2 * n].min().item() >= -1e-6 and z[2 * n].max().item() <= 1 + 1e-6
+    assert d.yv[g.src].item() == 1.0 and d.yv[g.dst].item() == 1.0
+
+
+@pytest.fixture(scope="module")
+def lattice_100k():
+    g = lattice_boxes(316, 317, seed=0)
+    assert g.num_vertices == 100174
+    return g
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_lattice_100k_single_handle(torch_gpu, oracle_lib, lattice_100k, dtype):
+    """BASELINE config 4's graph on one GPU: properties every iteration; f64: the residual trace of the first
+    iterations against the oracle at 1e-6 relative (same inner solver on both sides)."""
+    torch = torch_gpu
+    g = lattice_100k
+    d = _solver(g, dtype)
+    d.reset(max_it=40)
+    iters = 10 if dtype == "f64" else 6
+    for it in range(iters):
+        d.vertex_step()
+        sums = d.edge_step().clone()
+        _check_state_properties(torch, g, d, sums, dtype)
+        d.control()
+    cb = d.read_control()
+    assert cb.it == iters + 1 and cb.status == -1 and cb.inner_failures == 0
+    if dtype == "f64":
+        ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=iters, eps_abs=0.0, eps_rel=0.0, nthreads=16)
+        tr = d.trace[:iters].cpu().numpy()
+        assert ora["inner_failures"] == 0
+        for col, key in ((1, "pri_res_seq"), (2, "dual_res_seq")):
+            a, b = tr[:, col], ora[key][1:iters + 1]
+            assert np.max(np.abs(a - b) / b) <= 1e-6, key
+
+
+def test_lattice_100k_eight_partitions_match_single(torch_gpu, lattice_100k):
+    """BASELINE config 4 as it is sharded: 8 row strips = 8 handles (here on one GPU), halo columns copied by hand, the
+    five norms summed over the partitions -- against the single handle.  Same stop decisions, sums to 1e-3 (vertex
+    solves agree to solver accuracy), edge copies to 5e-4."""
+    torch = torch_gpu
+    from gcs_admm_amd.partition import build_partition, strip_owner
+    from gcs_admm_amd.solver import DeviceSolver
+    g = lattice_100k
+    world = 8
+    single = _solver(g, "f32")
+    single.reset(max_it=60)
+    owner = strip_owner(g, world)
+    parts = [build_partition(g, owner, r, world) for r in range(world)]
+    assert all(len(p.send_idx) <= 2 for p in parts)           # row strips: at most two neighbours
+    assert sum(p.graph.num_vertices for p in parts) == g.num_vertices
+    devs = [DeviceSolver(p.graph, "f32", device=0, num_incidences=p.num_incidences, inc_counted=p.inc_counted,
+                         edge_counted=p.edge_counted, nx_global=p.nx_global, nmu_global=p.nmu_global) for p in parts]
+    for d in devs:
+        d.reset(max_it=60)
+    idx = {(r, o): (torch.as_tensor(parts[r].recv_idx[o], device="cuda"), torch.as_tensor(parts[o].send_idx[r], device="cuda"))
+           for r in range(world) for o in parts[r].recv_idx}
+    for it in range(25):
+        single.vertex_step(); s_ref = single.edge_step().clone(); single.control()
+        for d in devs:
+            d.vertex_step()
+        for (r, o), (rix, six) in idx.items():
+            devs[r].copy.index_copy_(1, rix, devs[o].copy.index_select(1, six))
+        tot = torch.zeros(5, dtype=torch.float64, device="cuda")
+        for d in devs:
+            tot += d.edge_step()
+        assert torch.allclose(tot, s_ref, rtol=1e-3, atol=1e-9)
+        for d in devs:
+            d.control(tot)
+    cbs = [d.read_control() for d in devs] + [single.read_control()]
+    assert len({cb.it for cb in cbs}) == 1 and len({cb.status for cb in cbs}) == 1 and cbs[0].it == 26
+    assert all(cb.inner_failures == 0 for cb in cbs)
+    full = single.zedge.cpu().numpy()
+    for p, d in zip(parts, devs):
+        assert np.allclose(d.zedge.cpu().numpy(), full[:, p.edge_global], rtol=0, atol=5e-4)
+
+
+def test_lattice_r6_50k(torch_gpu, oracle_lib):
+    """BASELINE config 5 at full size (223 x 224 boxes in R^6, f32 state): the workgroup program; a few iterations with the
+    state properties, and the five sums of the first iteration against the oracle."""
+    torch = torch_gpu
+    g = lattice_boxes(223, 224, n=6, seed=0)
+    assert g.num_vertices == 49954 and g.n == 6
+    d = _solver(g, "f32")
+    q = d.query()
+    assert q["num_workgroup_vertices"] == g.num_vertices - 2 and q["num_waves"] == 0
+    d.reset(max_it=20)
+    first = None
+    for it in range(3):
+        d.vertex_step()
+        sums = d.edge_step().clone()
+        _check_state_properties(torch, g, d, sums, "f32")
+        if it == 0:
+            first = sums.cpu().numpy()
+        d.control()
+    cb = d.read_control()
+    assert cb.it == 4 and cb.status == -1 and cb.inner_failures == 0
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    assert o.vertex_step(1.0, 1.0, nthreads=16) == 0
+    ref = o.edge_step(1.0)
+    assert np.allclose(first, ref, rtol=1e-4, atol=1e-8)      # f32 storage of the state
+
+
+def test_benchmark4_tol_1e6_against_oracle(torch_gpu, oracle_lib):
+    """BASELINE config 2's second half: benchmark4, f64, eps_abs = eps_rel = 1e-6, MAX_IT lifted.  Iterations to the stop
+    within 1 % of the oracle's, relaxed cost within 2.5e-4 of the relaxation optimum the reference's monolithic solve
+    reports (classic_solver record, 32.629444)."""
+    case, g = load_fixture("benchmark4")
+    classic = case["golden_classic"]["cost"]
+    d = _solver(g)
+    res = d.solve(chunk=500, max_it=40000, eps_abs=1e-6, eps_rel=1e-6)
+    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=40000, eps_abs=1e-6, eps_rel=1e-6, nthreads=16)
+    assert res["status"] == "converged" and ora["status"] == 0 and res["inner_failures"] == 0
+    assert abs(res["iterations"] - ora["iterations"]) <= 0.01 * ora["iterations"], (res["iterations"], ora["iterations"])
+    assert abs(res["cost"] - classic) <= 2.5e-4 * classic
+    assert abs(res["cost"] - ora["cost"]) <= 1e-5 * classic
+
+
+def test_lattice_10k_f32_runs_to_the_same_stop(torch_gpu, oracle_lib):
+    """BASELINE config 3 under the reference's stop rule: f32 state, f64 state and the oracle stop at the same iteration,
+    with the same relaxed cost (f32: to storage precision)."""
+    g = lattice_boxes(100, 100, seed=0)
+    r64 = _solver(g, "f64").solve(chunk=100)
+    r32 = _solver(g, "f32").solve(chunk=100)
+    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(nthreads=16)
+    assert r64["status"] == r32["status"] == "converged" and ora["status"] == 0
+    assert r64["iterations"] == r32["iterations"] == ora["iterations"]
+    assert r64["inner_failures"] == 0 and r32["inner_failures"] == 0
+    assert abs(r64["cost"] - ora["cost"]) <= 1e-6 * ora["cost"]
+    assert abs(r32["cost"] - r64["cost"]) <= 1e-4 * r64["cost"]
+
+
+def test_inner_failure_keeps_previous_copy(torch_gpu):
+    """an inner solve that hits its iteration limit keeps the vertex's previous copy columns and is counted
+    (admm_solver_v3.py:524-538 intent): with ipm_max_iter = 2 every generic vertex fails, the state stays finite and the
+    generic vertices' columns stay what they were (zero)."""
+    torch = torch_gpu
+    for program in ("wavefront", "workgroup"):
+        g = lattice_boxes(8, 7, seed=3)
+        d = _solver(g, program=program)
+        d.reset(max_it=10, ipm_max_iter=2)
+        for it in range(3):
+            d.vertex_step()
+            d.edge_step()
+            d.control()
+        cb = d.read_control()
+        n_generic = g.num_vertices - 2 - int(((np.diff(g.inc_ptr) == 0)).sum())
+        assert cb.inner_failures >= n_generic - 4 and cb.status == -1
+        assert torch.isfinite(d.copy).all() and torch.isfinite(d.zedge).all() and torch.isfinite(d.mu).all()
+        deg = np.diff(g.inc_ptr)
+        for v in range(2, g.num_vertices):
+            if deg[v] >= 2:
+                sl = slice(int(g.inc_ptr[v]), int(g.inc_ptr[v + 1]))
+                assert d.copy[:, sl].abs().max().item() == 0.0 and d.yv[v].item() == 0.0
+                break
+
+
+def test_terminal_with_extent_is_refused(torch_gpu):
+    """'s' / 't' are treated as points (utils.py:12-28 makes them boxes of half-width 1e-6): a terminal that is a real region
+    is refused with GCSADMM_ERR_UNSUPPORTED instead of being silently replaced by its centre"""
+    from gcs_admm_amd import solver
+    from gcs_admm_amd.graph import convert_pt_to_polytope, graph_from_sets
+    A = np.vstack([np.eye(2), -np.eye(2)])
+    As, bs = {}, {}
+    As['s'], bs['s'] = A, np.array([0.5, 0.5, 0.5, 0.5])                  # a box of half-width 0.5, not a point
+    As['t'], bs['t'] = convert_pt_to_polytope(np.array([3.0, 0.0]))
+    As[0], bs[0] = A, np.array([4.0, 1.0, 1.0, 1.0])
+    g = graph_from_sets(As, bs, 2)
+    with pytest.raises(solver.GcsAdmmError, match="point"):
+        _solver(g)

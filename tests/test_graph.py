@@ -63,3 +63,46 @@ def test_lattice_generator():
     assert all((w, u) in pairs for u, w in pairs)
     g2 = G.lattice_boxes(20, 12, seed=0)
     assert np.array_equal(g.poly_b, g2.poly_b) and np.array_equal(g.edge_tail, g2.edge_tail)
+
+
+def test_device_graph_builder_acts_on_lp_status():
+    """build_graph_device never trusts an LP that hit its iteration limit (status -1): a failed bounding-box side is
+    opened up (it would otherwise be an interior iterate = a box that is too small, and the sweep would drop real
+    neighbours), a failed overlap LP is decided again on the host, a failed centre LP is an error.  The device is
+    replaced by a stand-in scene that reports such failures; no GPU needed."""
+    import pytest
+    from gcs_admm_amd import scene as sc
+    from gcs_admm_amd.graph import build_graph
+    A = np.vstack([np.eye(2), -np.eye(2)])
+    As = {k: A for k in range(4)}
+    bs = {0: np.array([1.0, 1.0, 0.0, 0.0]), 1: np.array([2.0, 1.0, -0.9, 0.0]),      # 0-1 overlap, 1-2 overlap, 3 apart
+          2: np.array([3.0, 1.0, -1.9, 0.0]), 3: np.array([9.0, 9.0, -8.0, -8.0])}
+    _, E_ref, _, _ = build_graph(As, bs)
+
+    class FakeScene:
+        def __init__(self, mode): self.mode = mode
+        def centers(self):
+            cen = np.array([[0.5, 0.5], [1.45, 0.5], [2.45, 0.5], [8.5, 8.5]])
+            st = np.zeros(4, np.int32)
+            if self.mode == "center": st[2] = -1
+            return cen, np.full(4, 0.4), st
+        def bounds(self, cen):
+            lo = np.array([[0, 0], [0.9, 0], [1.9, 0], [8, 8]], float); hi = np.array([[1, 1], [2, 1], [3, 1], [9, 9]], float)
+            st = np.zeros((4, 2, 2), np.int32)
+            if self.mode == "bounds":          # region 1's upper x bound stopped early at an interior point
+                hi[1, 0] = 1.5; st[1, 0, 1] = -1
+            return lo, hi, st
+        def overlaps(self, pa, pb, tol, cen):
+            flags = np.array([1 if (min(a, b), max(a, b)) in {(0, 1), (1, 2)} else 0 for a, b in zip(pa, pb)], np.uint8)
+            st = np.zeros(len(pa), np.int32)
+            if self.mode == "overlap":         # every LP "failed" and reports the wrong answer
+                st[:] = -1; flags[:] = 1 - flags
+            return flags, st
+
+    for mode in ("ok", "bounds", "overlap"):
+        stats = {}
+        _, E, _, _, _ = sc.build_graph_device(As, bs, scene=FakeScene(mode), stats=stats)
+        assert E == E_ref, mode
+        assert (stats["bounds_opened"] > 0) == (mode == "bounds") and (stats["overlaps_redone_on_host"] > 0) == (mode == "overlap")
+    with pytest.raises(sc.GcsAdmmError, match="centre LP"):
+        sc.build_graph_device(As, bs, scene=FakeScene("center"))

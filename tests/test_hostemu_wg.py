@@ -1,0 +1,98 @@
+"""The workgroup-cooperative vertex program (gcs_admm_amd/csrc/vertex_wg.h) compiled for the HOST (tests/hostemu/wg_emu.cpp):
+every parallel region runs its tasks serially, which equals the GPU execution as long as the tasks of a region are
+independent.  Checked here without a GPU: (1) the algorithm against the CPU oracle (same interior-point method), for n = 2, 3, 6,
+general polygons and boxes; (2) task-order independence: ascending and descending task order agree to round-off (the only
+order-dependent operations are the floating-point sums of the workgroup reductions); (3) no read of unwritten LDS
+(the emulation poisons it with NaN).  The GPU parity tests proper are test_gpu_parity.py / test_gpu_configs.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gcs_admm_amd.cases import load_fixture
+from gcs_admm_amd.graph import lattice_boxes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "gcs_admm_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    src = os.path.join(HERE, "hostemu", "wg_emu.cpp")
+    deps = [src, os.path.join(CSRC, "vertex_wg.h"), os.path.join(CSRC, "gcs_math.h")]
+    out = []
+    for name, flags in (("libwgemu.so", []), ("libwgemu_rev.so", ["-DGCS_WG_REVERSE"])):
+        so = os.path.join(HERE, "hostemu", name)
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC] + flags + [src, "-o", so])
+        out.append(C.CDLL(so))
+    return out
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def wg_step(lib, fn, g, zedge, mu, rho=1.0, mu_scale=1.0, max_iter=60):
+    c, NI, V = g.c, 2 * g.num_edges, g.num_vertices
+    copy = np.zeros((c, NI)); xv = np.zeros((V, 2 * g.n)); zv = np.zeros_like(xv); yv = np.zeros(V)
+    cnt = np.zeros(2, dtype=np.int32); gen = np.zeros(V, dtype=np.int32)
+    st = np.zeros(V, dtype=np.int32); it = np.zeros(V, dtype=np.int32)
+    r = getattr(lib, fn)(g.n, V, g.num_edges, NI, _p(g.inc_ptr), _p(g.inc_edge), _p(g.inc_out), _p(g.poly_ptr), _p(g.poly_A),
+                         _p(g.poly_b), _p(g.interior), g.src, g.dst, _p(zedge), _p(mu), C.c_double(rho), C.c_double(mu_scale),
+                         C.c_double(1e-4), C.c_double(1e-9), max_iter, _p(copy), _p(xv), _p(zv), _p(yv), _p(cnt), _p(gen),
+                         _p(st), _p(it))
+    assert r == 0
+    return copy, xv, zv, yv, cnt, gen == 1, st, it
+
+
+CASES = [("benchmark1", None, 12, 2e-3), ("benchmark4", None, 12, 2e-3), ("test_autogen2", None, 8, 2e-3),
+         ("lattice n=2", (5, 4, 2), 8, 1e-6), ("lattice n=3", (4, 3, 3), 6, 1e-6), ("lattice n=6", (4, 3, 6), 5, 1e-6)]
+
+
+@pytest.mark.parametrize("name,lat,steps,tol", CASES)
+def test_workgroup_program_matches_oracle_and_is_order_independent(libs, oracle_lib, name, lat, steps, tol):
+    fwd, rev = libs
+    g = lattice_boxes(lat[0], lat[1], n=lat[2], seed=1) if lat else load_fixture(name)[1]
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    diffs = []
+    for it in range(steps):
+        z0, m0 = o.zedge.copy(), o.mu.copy()
+        a = wg_step(fwd, "wg_emu_vertex_step", g, z0, m0)
+        b = wg_step(rev, "wg_emu_vertex_step_rev", g, z0, m0)
+        assert o.vertex_step(1.0, 1.0) == 0
+        gen = a[5]
+        assert a[4][0] == 0 and (a[6][gen] == 0).all()
+        mask = np.zeros(2 * g.num_edges, bool)
+        for v in np.nonzero(gen)[0]:
+            mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
+        assert np.isfinite(a[0][:, mask]).all()            # a read of unwritten (NaN-poisoned) LDS would surface here
+        diffs.append(np.abs(a[0][:, mask] - o.copy[:, mask]).max())
+        assert np.abs(a[3][gen] - o.yv[gen]).max() <= 5e-4
+        # same tasks in the opposite order: identical up to the summation order of the reductions
+        assert np.abs(a[0] - b[0]).max() <= max(10 * diffs[-1], 1e-9)
+        o.edge_step(1.0)
+    diffs = np.array(diffs)
+    assert diffs.max() <= tol and np.median(diffs) <= max(1e-5, tol * 1e-2)
+
+
+def test_inner_failure_keeps_previous_outputs(libs):
+    """an inner solve that runs out of iterations writes nothing (admm_solver_v3.py:524-538 intent) and is counted"""
+    fwd, _ = libs
+    g = lattice_boxes(4, 3, seed=2)
+    z = np.zeros((g.c, g.num_edges)); mu = np.zeros((g.c, 2 * g.num_edges))
+    copy, xv, zv, yv, cnt, gen, st, it = wg_step(fwd, "wg_emu_vertex_step", g, z, mu, max_iter=2)
+    assert cnt[0] == gen.sum() and (st[gen] == -1).all() and (it[gen] == 2).all()
+    assert not copy.any() and not yv.any()
+
+
+def test_lds_budget_of_the_named_configs(libs):
+    """LDS per workgroup: BASELINE config 5 (R^6, 8 incident edges, 12 facets) must leave room for TWO workgroups per CU
+    (160 KB); benchmark4's largest vertex and a degree-80 box vertex must fit one."""
+    fwd, _ = libs
+    assert 8 * fwd.wg_emu_lds_doubles(6, 9, 12) <= 80 * 1024
+    assert 8 * fwd.wg_emu_lds_doubles(2, 11, 7) <= 32 * 1024
+    assert 8 * fwd.wg_emu_lds_doubles(2, 81, 4) <= 160 * 1024

@@ -17,10 +17,13 @@ ADMM_KEYS = ("iterations", "rho_seq", "pri_res_seq", "dual_res_seq")
 
 
 def save_data(data_file, As, bs, solve_time, cost, x_v_sol, y_v_sol, x_v_rounded, y_v_rounded, ADMM=True,
-              iterations=None, rho_seq=None, pri_res_seq=None, dual_res_seq=None):
+              iterations=None, rho_seq=None, pri_res_seq=None, dual_res_seq=None, **extra):
+    """The reference's record (utils.py:197-233): same keys, same order.  ``extra`` appends fields the reference does
+    not have (e.g. ``loop_wall_time``, ``inner_failures``); its post-processing script reads by key and ignores them."""
     record = dict(zip(RECORD_KEYS, (As, bs, solve_time, cost, x_v_sol, y_v_sol, x_v_rounded, y_v_rounded, ADMM)))
     if ADMM:
         record.update(zip(ADMM_KEYS, (iterations, rho_seq, pri_res_seq, dual_res_seq)))
+    record.update(extra)
     with open(data_file, "wb") as f:
         pickle.dump(record, f)
 
