@@ -74,14 +74,16 @@ struct ControlParams {
 };
 
 // admm_solver_v3.py:697-733 on the five (globally reduced) sums; one thread
-__device__ void control_body(gcsadmm_control_block *cb, const double *sums, const ControlParams &p, int *counters, double *trace)
+// global_fails: the inner-failure count comes with the (all-reduced) sums as sums[5] instead of from this handle's counter
+__device__ void control_body(gcsadmm_control_block *cb, const double *sums, const ControlParams &p, int *counters, double *trace,
+                             bool global_fails = false)
 {
     if (cb->status != GCSADMM_RUNNING) return;
     double s[5];
     for (int k = 0; k < 5; ++k) { s[k] = sums[k]; cb->sums[k] = s[k]; }
     const int it = cb->it;
     double rho = cb->rho;
-    const int fails = counters[0], iters = counters[1];
+    const int fails = global_fails ? (int)(sums[5] + 0.5) : counters[0], iters = counters[1];
     counters[0] = 0; counters[1] = 0;
     cb->inner_failures = fails; cb->inner_iters = iters;
     const double tot = s[0] + s[1] + s[2] + s[3] + s[4];
@@ -106,10 +108,10 @@ __device__ void control_body(gcsadmm_control_block *cb, const double *sums, cons
     if (it + 1 > p.max_it) cb->status = GCSADMM_MAX_IT;
 }
 
-__global__ void control_kernel(gcsadmm_control_block *cb, const double *sums, ControlParams p, int *counters, double *trace)
+__global__ void control_kernel(gcsadmm_control_block *cb, const double *sums, ControlParams p, int *counters, double *trace, bool global_fails)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    control_body(cb, sums, p, counters, trace);
+    control_body(cb, sums, p, counters, trace, global_fails);
 }
 
 // FUSED (single workgroup, i.e. at most EDGE_BLOCK edges: gcsadmm_run on small graphs): the workgroup also does the
@@ -284,7 +286,64 @@ struct gcsadmm_handle_s {
     double *d_partials = nullptr, *d_sums = nullptr;
     std::vector<hipEvent_t> events;
     std::string err;
+    // vertex partition across GPUs (gcsadmm_attach_comm): RCCL communicator, halo index lists and message buffers
+    void *comm = nullptr;             // ncclComm_t
+    int rank = 0, world = 1;
+    std::vector<int> peers, peer_cnt, peer_off;   // neighbour ranks; columns per peer; first column of each peer's block
+    int n_send = 0, n_recv = 0;       // halo columns sent / received per iteration
+    int *d_send_cols = nullptr, *d_send_base = nullptr, *d_send_stride = nullptr;
+    int *d_recv_cols = nullptr, *d_recv_base = nullptr, *d_recv_stride = nullptr;
+    void *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+    double *d_sums6 = nullptr;        // the five norms + the inner-failure count, all-reduced together
 };
+
+// ---- RCCL, bound at run time ----
+// The library is not linked against librccl: a process that already carries an RCCL (PyTorch-ROCm ships its own copy with the
+// SONAME of /opt/rocm's) must not end up with two, and a single-GPU user needs none.  dlopen returns the copy that is already
+// loaded, or loads the system one.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+    bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce; }
+};
+RcclApi &rccl()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) { a.err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return a; }
+#define RCCL_SYM(f) a.f = (decltype(a.f))dlsym(a.lib, "nccl" #f)
+        RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommDestroy); RCCL_SYM(GroupStart); RCCL_SYM(GroupEnd);
+        RCCL_SYM(Send); RCCL_SYM(Recv); RCCL_SYM(AllReduce); RCCL_SYM(GetErrorString);
+#undef RCCL_SYM
+        if (!a.ok()) a.err = "librccl lacks an expected symbol";
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+#define NCCLCHK(h, call)                                                                             \
+    do {                                                                                             \
+        ncclResult_t r_ = (call);                                                                    \
+        if (r_ != ncclSuccess) {                                                                     \
+            (h)->err = std::string(#call) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r_) : "RCCL error"); \
+            return GCSADMM_ERR_HIP;                                                                  \
+        }                                                                                            \
+    } while (0)
+
 
 static std::string g_create_error;
 
@@ -404,6 +463,75 @@ static VertexLaunchDesc make_launch_desc(gcsadmm_handle h, const gcsadmm_state *
     return d;
 }
 
+// ---- halo of a vertex partition: host-side helpers (C++ linkage) ----
+static gcsadmm_status halo_upload(gcsadmm_handle h, const gcsadmm_halo_desc *hd)
+{
+    const int P = hd->num_peers, c = h->c;
+    h->peers.assign(hd->peer_rank, hd->peer_rank + P);
+    h->peer_cnt.resize(P); h->peer_off.resize(P);
+    h->n_send = P ? hd->send_ptr[P] : 0; h->n_recv = P ? hd->recv_ptr[P] : 0;
+    if (h->n_send != h->n_recv) { h->err = "halo lists: a partition sends and receives one column per cut edge and neighbour"; return GCSADMM_ERR_BAD_ARG; }
+    std::vector<int> sbase(std::max(h->n_send, 1)), sstride(std::max(h->n_send, 1));
+    for (int p = 0; p < P; ++p) {
+        const int lo = hd->send_ptr[p], cnt = hd->send_ptr[p + 1] - lo;
+        if (cnt < 0 || hd->recv_ptr[p + 1] - hd->recv_ptr[p] != cnt || hd->recv_ptr[p] != lo) { h->err = "halo lists: send and receive counts per peer must agree"; return GCSADMM_ERR_BAD_ARG; }
+        if (hd->peer_rank[p] < 0 || hd->peer_rank[p] >= h->world || hd->peer_rank[p] == h->rank) { h->err = "halo lists: bad peer rank"; return GCSADMM_ERR_BAD_ARG; }
+        h->peer_cnt[p] = cnt; h->peer_off[p] = lo;
+        for (int j = 0; j < cnt; ++j) { sbase[lo + j] = lo * c + j; sstride[lo + j] = cnt; }     // block of peer p: [c][cnt] at lo * c
+    }
+    for (int j = 0; j < h->n_send; ++j) {
+        if (hd->send_cols[j] < 0 || hd->send_cols[j] >= h->NI_owned) { h->err = "halo lists: send column is not an owned incidence"; return GCSADMM_ERR_BAD_ARG; }
+        if (hd->recv_cols[j] < h->NI_owned || hd->recv_cols[j] >= h->NI) { h->err = "halo lists: receive column is not a ghost column"; return GCSADMM_ERR_BAD_ARG; }
+    }
+    const size_t esz = h->dtype == GCSADMM_F64 ? 8 : 4;
+    HIPCHK(h, upload(&h->d_send_cols, hd->send_cols, (size_t)h->n_send));
+    HIPCHK(h, upload(&h->d_recv_cols, hd->recv_cols, (size_t)h->n_recv));
+    HIPCHK(h, upload(&h->d_send_base, sbase.data(), (size_t)h->n_send));
+    HIPCHK(h, upload(&h->d_send_stride, sstride.data(), (size_t)h->n_send));
+    HIPCHK(h, upload(&h->d_recv_base, sbase.data(), (size_t)h->n_recv));        // same block layout on the receiving side
+    HIPCHK(h, upload(&h->d_recv_stride, sstride.data(), (size_t)h->n_recv));
+    HIPCHK(h, hipMalloc(&h->d_sendbuf, std::max<size_t>((size_t)h->n_send * c * esz, 16)));
+    HIPCHK(h, hipMalloc(&h->d_recvbuf, std::max<size_t>((size_t)h->n_recv * c * esz, 16)));
+    HIPCHK(h, upload(&h->d_sums6, (const double *)nullptr, 6));
+    return GCSADMM_OK;
+}
+
+template <class T> static gcsadmm_status halo_pack(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
+{
+    if (h->n_send == 0) return GCSADMM_OK;
+    const int tot = h->c * h->n_send;
+    hipLaunchKernelGGL((halo_pack_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, s, h->c, h->n_send, h->NI, h->d_send_cols,
+                       h->d_send_base, h->d_send_stride, (const T *)st->copy, (T *)h->d_sendbuf, h->d_cb);
+    HIPCHK(h, hipGetLastError());
+    return GCSADMM_OK;
+}
+template <class T> static gcsadmm_status halo_unpack(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
+{
+    if (h->n_recv == 0) return GCSADMM_OK;
+    const int tot = h->c * h->n_recv;
+    hipLaunchKernelGGL((halo_unpack_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, s, h->c, h->n_recv, h->NI, h->d_recv_cols,
+                       h->d_recv_base, h->d_recv_stride, (const T *)h->d_recvbuf, (T *)st->copy, h->d_cb);
+    HIPCHK(h, hipGetLastError());
+    return GCSADMM_OK;
+}
+
+// the grouped point-to-point exchange of the packed halo (one message per neighbour and direction)
+static gcsadmm_status halo_transfer(gcsadmm_handle h, hipStream_t s)
+{
+    if (h->peers.empty()) return GCSADMM_OK;
+    if (!h->comm) { h->err = "halo exchange needs a communicator (gcsadmm_attach_comm with an id)"; return GCSADMM_ERR_BAD_ARG; }
+    const ncclDataType_t dt = h->dtype == GCSADMM_F64 ? ncclFloat64 : ncclFloat32;
+    const size_t esz = h->dtype == GCSADMM_F64 ? 8 : 4;
+    NCCLCHK(h, rccl().GroupStart());
+    for (size_t p = 0; p < h->peers.size(); ++p) {
+        const size_t off = (size_t)h->peer_off[p] * h->c * esz, cnt = (size_t)h->peer_cnt[p] * h->c;
+        NCCLCHK(h, rccl().Send((const char *)h->d_sendbuf + off, cnt, dt, h->peers[p], (ncclComm_t)h->comm, s));
+        NCCLCHK(h, rccl().Recv((char *)h->d_recvbuf + off, cnt, dt, h->peers[p], (ncclComm_t)h->comm, s));
+    }
+    NCCLCHK(h, rccl().GroupEnd());
+    return GCSADMM_OK;
+}
+
 extern "C" {
 
 const char *gcsadmm_last_error(gcsadmm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -417,6 +545,10 @@ void gcsadmm_destroy(gcsadmm_handle h)
                     h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_send_cols, (void *)h->d_send_base, (void *)h->d_send_stride, (void *)h->d_recv_cols, (void *)h->d_recv_base,
+                    (void *)h->d_recv_stride, h->d_sendbuf, h->d_recvbuf, (void *)h->d_sums6})
+        if (p) (void)hipFree(p);
+    if (h->comm && rccl().ok()) (void)rccl().CommDestroy((ncclComm_t)h->comm);
     for (auto ev : h->events) (void)hipEventDestroy(ev);
     delete h;
 }
@@ -497,9 +629,10 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     }
     int n_generic = 0;
     for (int v = 0; v < V; ++v) n_generic += !is_special(v);
-    // Crossover of the two programs on n = 2 (measured on box lattices, profiles/r02): below ~1500 generic vertices one
-    // workgroup per vertex is faster (every CU holds several), above it the wavefront program's packing wins.
-    constexpr int WG_AUTO_MAX = 1536;
+    // Crossover of the two programs on n = 2 (measured on box lattices, profiles/r02/README.md: 576 vertices 4 050 vs 3 050 it/s,
+    // 1 024 vertices 2 470 vs 2 940): up to ~768 generic vertices one workgroup per vertex is faster (latency: every region of
+    // a solve runs 256 threads wide), above it the wavefront program's packing of several vertices per wavefront wins.
+    constexpr int WG_AUTO_MAX = 768;
     if (g->vertex_program < 0 || g->vertex_program > 2) return fail(GCSADMM_ERR_BAD_ARG, "vertex_program must be 0, 1 or 2");
     const bool prefer_wg = g->vertex_program == 2 || (g->vertex_program == 0 && n_generic <= WG_AUTO_MAX);
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx, wg_vtx;
@@ -675,7 +808,7 @@ gcsadmm_status gcsadmm_control(gcsadmm_handle h, const double *sums_dev, double 
     USE_DEVICE(h);
     const gcsadmm_params &p = h->params;
     ControlParams cp{p.tau_incr, p.tau_decr, p.nu, p.eps_abs, p.eps_rel, h->nx, h->nmu, p.it_rho_limit, p.max_it};
-    hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d_cb, sums_dev, cp, h->d_counters, trace_dev);
+    hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d_cb, sums_dev, cp, h->d_counters, trace_dev, false);
     HIPCHK(h, hipGetLastError());
     return GCSADMM_OK;
 }
@@ -690,6 +823,103 @@ gcsadmm_status gcsadmm_run(gcsadmm_handle h, const gcsadmm_state *st, int32_t k,
         s = h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, h->d_sums, (hipStream_t)stream, true, trace_dev)
                                     : launch_edge<float>(h, st, h->d_sums, (hipStream_t)stream, true, trace_dev);
         if (s != GCSADMM_OK) return s;
+    }
+    return GCSADMM_OK;
+}
+
+// =================================================================================================
+// vertex partitions across GPUs: one handle per rank, RCCL over xGMI.
+// Per iteration, all on one stream with no host synchronisation:
+//   vertex step -> pack the cut edges' copies per neighbour -> grouped ncclSend / ncclRecv -> unpack into the ghost columns
+//   -> edge step on local + ghost columns -> ncclAllReduce(sum) of the five norms and the inner-failure count (6 doubles)
+//   -> control (every rank takes the same decision from the same numbers).
+// Both messages are latency-bound at every configuration of BASELINE.json (about 25 KB per boundary of the 100k lattice,
+// 48 bytes for the all-reduce).
+// =================================================================================================
+gcsadmm_status gcsadmm_comm_unique_id(void *id128)
+{
+    if (!id128) return GCSADMM_ERR_BAD_ARG;
+    if (!rccl().ok()) { g_create_error = rccl().err; return GCSADMM_ERR_HIP; }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return GCSADMM_ERR_HIP; }
+    std::memcpy(id128, &id, sizeof(id));
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_attach_comm(gcsadmm_handle h, int32_t rank, int32_t world, const void *id128, const gcsadmm_halo_desc *halo)
+{
+    if (!h || !halo || world < 1 || rank < 0 || rank >= world) { if (h) h->err = "bad communicator arguments"; return GCSADMM_ERR_BAD_ARG; }
+    if (h->d_sums6) { h->err = "a communicator is already attached"; return GCSADMM_ERR_BAD_ARG; }
+    if (halo->num_peers < 0 || (halo->num_peers > 0 && (!halo->peer_rank || !halo->send_ptr || !halo->recv_ptr || !halo->send_cols || !halo->recv_cols))) {
+        h->err = "null halo array"; return GCSADMM_ERR_BAD_ARG;
+    }
+    USE_DEVICE(h);
+    h->rank = rank; h->world = world;
+    gcsadmm_status st = halo_upload(h, halo);
+    if (st != GCSADMM_OK) return st;
+    if (id128) {      // id128 == NULL: no communicator (the host moves the packed buffers itself; gcsadmm_run_partitioned needs one)
+        if (!rccl().ok()) { h->err = rccl().err; return GCSADMM_ERR_HIP; }
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        ncclComm_t comm = nullptr;
+        NCCLCHK(h, rccl().CommInitRank(&comm, world, id, rank));
+        h->comm = comm;
+    }
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_halo_pack(gcsadmm_handle h, const gcsadmm_state *st, void *stream)
+{
+    if (!state_ok(h, st) || !h->d_sums6) { if (h) h->err = "no halo attached"; return GCSADMM_ERR_BAD_ARG; }
+    USE_DEVICE(h);
+    return h->dtype == GCSADMM_F64 ? halo_pack<double>(h, st, (hipStream_t)stream) : halo_pack<float>(h, st, (hipStream_t)stream);
+}
+gcsadmm_status gcsadmm_halo_unpack(gcsadmm_handle h, const gcsadmm_state *st, void *stream)
+{
+    if (!state_ok(h, st) || !h->d_sums6) { if (h) h->err = "no halo attached"; return GCSADMM_ERR_BAD_ARG; }
+    USE_DEVICE(h);
+    return h->dtype == GCSADMM_F64 ? halo_unpack<double>(h, st, (hipStream_t)stream) : halo_unpack<float>(h, st, (hipStream_t)stream);
+}
+gcsadmm_status gcsadmm_halo_buffers(gcsadmm_handle h, void **send_buf, void **recv_buf, int64_t *num_elements)
+{
+    if (!h || !h->d_sums6) { if (h) h->err = "no halo attached"; return GCSADMM_ERR_BAD_ARG; }
+    if (send_buf) *send_buf = h->d_sendbuf;
+    if (recv_buf) *recv_buf = h->d_recvbuf;
+    if (num_elements) *num_elements = (int64_t)h->c * h->n_send;
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_halo_exchange(gcsadmm_handle h, const gcsadmm_state *st, void *stream)
+{
+    if (!state_ok(h, st) || !h->d_sums6) { if (h) h->err = "no halo attached"; return GCSADMM_ERR_BAD_ARG; }
+    USE_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    gcsadmm_status r;
+    if ((r = h->dtype == GCSADMM_F64 ? halo_pack<double>(h, st, s) : halo_pack<float>(h, st, s)) != GCSADMM_OK) return r;
+    if ((r = halo_transfer(h, s)) != GCSADMM_OK) return r;
+    return h->dtype == GCSADMM_F64 ? halo_unpack<double>(h, st, s) : halo_unpack<float>(h, st, s);
+}
+
+gcsadmm_status gcsadmm_run_partitioned(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream)
+{
+    if (!state_ok(h, st) || k < 0) return GCSADMM_ERR_BAD_ARG;
+    if (!h->d_sums6) { h->err = "gcsadmm_attach_comm has not been called"; return GCSADMM_ERR_BAD_ARG; }
+    USE_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    const gcsadmm_params &pp = h->params;
+    const ControlParams cp{pp.tau_incr, pp.tau_decr, pp.nu, pp.eps_abs, pp.eps_rel, h->nx, h->nmu, pp.it_rho_limit, pp.max_it};
+    for (int i = 0; i < k; ++i) {
+        gcsadmm_status r;
+        if ((r = gcsadmm_vertex_step(h, st, stream)) != GCSADMM_OK) return r;
+        if ((r = gcsadmm_halo_exchange(h, st, stream)) != GCSADMM_OK) return r;
+        r = h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, h->d_sums6, s) : launch_edge<float>(h, st, h->d_sums6, s);
+        if (r != GCSADMM_OK) return r;
+        hipLaunchKernelGGL(fails_to_sums_kernel, dim3(1), dim3(1), 0, s, h->d_sums6, h->d_counters, h->d_cb);
+        if (!h->comm && h->world > 1) { h->err = "gcsadmm_run_partitioned needs a communicator (gcsadmm_attach_comm with an id)"; return GCSADMM_ERR_BAD_ARG; }
+        if (h->comm) NCCLCHK(h, rccl().AllReduce(h->d_sums6, h->d_sums6, 6, ncclFloat64, ncclSum, (ncclComm_t)h->comm, s));
+        hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, s, h->d_cb, h->d_sums6, cp, h->d_counters, trace_dev, true);
+        HIPCHK(h, hipGetLastError());
     }
     return GCSADMM_OK;
 }

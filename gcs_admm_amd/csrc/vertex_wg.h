@@ -35,7 +35,11 @@ using gcs_math::rcp1;
 using gcs_math::rsqrt_nr;
 using gcs_math::sqrt_nr;
 
-constexpr int WG_THREADS = 256;
+#ifndef GCS_WG_THREADS
+#define GCS_WG_THREADS 256
+#endif
+constexpr int WG_THREADS = GCS_WG_THREADS;        // threads per workgroup (a power of two, whole wavefronts)
+constexpr int WG_WAVES = WG_THREADS / 64;
 constexpr double CHOL_SKIP = 1e-12;
 constexpr double REG_DELTA = 1e-7;   // Tikhonov term on every centred unknown except t (oracle/gcs_oracle.c REG_DELTA)
 
@@ -132,7 +136,7 @@ template <int N> struct WL {
                          PIVS = BXS + pad2(2 * NW * NX), BG = PIVS + pad2(2 * NW), XBG = BG + pad2(2 * NW), XBX = XBG + pad2(2 * NX),
                          XS = XBX + pad2(2 * NX * NX), RP = XS + pad2(NX * N), VV = RP + pad2(2 * NW), WW = VV + pad2(2 * NW), M = WW + pad2(2 * NW),
                          MINV = M + pad2(NB1 * NB1), PIVM = MINV + pad2(NB1 * NB1), RHS = PIVM + pad2(NB1), SOL = RHS + pad2(NB1),
-                         SOC = SOL + pad2(NB1), SC = SOC + pad2(WSoc<N>::SIZE), RED = SC + pad2(SC_N), FIXED = RED + 36;
+                         SOC = SOL + pad2(NB1), SC = SOC + pad2(WSoc<N>::SIZE), RED = SC + pad2(SC_N), FIXED = RED + 3 * 3 * WG_WAVES;
     // per-unit block (offsets from the unit's base); the three facet-row arrays (4m each) follow at ROWS
     static constexpr int P = 0, DW = P + pad2(NW), TG = DW + pad2(NW), TF = TG + pad2(NW), LB = TF + pad2(N), KB = LB + 2, DLB = KB + 2,
                          PIV = DLB + 2, G0 = PIV + pad2(NW), GU = G0 + pad2(NW), GX = GU + pad2(NW), TE = GX + pad2(NX),
@@ -198,15 +202,14 @@ GCS_HD Red3 wg_reduce(Red3 v, double *red, int &phase)
     w.mn = fmin(fmin(lane_bcast(v.mn, 15), lane_bcast(v.mn, 31)), fmin(lane_bcast(v.mn, 47), lane_bcast(v.mn, 63)));
     w.s1 = (lane_bcast(v.s1, 15) + lane_bcast(v.s1, 31)) + (lane_bcast(v.s1, 47) + lane_bcast(v.s1, 63));
     w.s2 = (lane_bcast(v.s2, 15) + lane_bcast(v.s2, 31)) + (lane_bcast(v.s2, 47) + lane_bcast(v.s2, 63));
-    double *buf = red + phase * 12;
+    double *buf = red + phase * (3 * WG_WAVES);
     phase = phase == 2 ? 0 : phase + 1;
     const int wave = (int)threadIdx.x >> 6;
     if (((int)threadIdx.x & 63) == 0) { buf[wave * 3 + 0] = w.mn; buf[wave * 3 + 1] = w.s1; buf[wave * 3 + 2] = w.s2; }
     __syncthreads();
-    Red3 r;
-    r.mn = fmin(fmin(buf[0], buf[3]), fmin(buf[6], buf[9]));
-    r.s1 = (buf[1] + buf[4]) + (buf[7] + buf[10]);
-    r.s2 = (buf[2] + buf[5]) + (buf[8] + buf[11]);
+    Red3 r{buf[0], buf[1], buf[2]};
+#pragma unroll
+    for (int q = 1; q < WG_WAVES; ++q) { r.mn = fmin(r.mn, buf[3 * q]); r.s1 += buf[3 * q + 1]; r.s2 += buf[3 * q + 2]; }
     return r;
 #else
     (void)red; (void)phase;

@@ -17,7 +17,7 @@ using namespace gcsadmm_k;
 using gcs_wg::WG_THREADS;
 
 template <int N, class T>
-__global__ __launch_bounds__(WG_THREADS, 2) void vertex_wg_kernel(gcs_wg::WgArgs<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
+__global__ __launch_bounds__(WG_THREADS, (gcs_wg::WG_THREADS <= 256 ? 2 : 1)) void vertex_wg_kernel(gcs_wg::WgArgs<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (cb->status != GCSADMM_RUNNING) return;

@@ -178,3 +178,29 @@ class PartitionedLoop:
             cb = self.backend.read_control()
             if cb.status != -1 or done >= max_it:
                 return cb
+
+
+def device_partition(g: GcsGraph, rank: int, world: int, state_dtype: str = "f32", device=None, group=None, owner=None, **kw):
+    """One rank's DeviceSolver for a strip partition of ``g``, joined to an RCCL communicator through the C ABI
+    (gcsadmm_attach_comm).  The 128-byte communicator id is created by rank 0 and distributed with ``torch.distributed``
+    (which must be initialised when world > 1; any backend: it only carries the 128 bytes).  The loop itself then runs
+    entirely behind the ABI: ``solver.enqueue_partitioned(k)`` / ``solver.solve_partitioned()``.
+    Returns (LocalPartition, DeviceSolver)."""
+    import torch
+    from .solver import DeviceSolver
+    owner = strip_owner(g, world) if owner is None else owner
+    part = build_partition(g, owner, rank, world)
+    dev = DeviceSolver(part.graph, state_dtype, device=device, num_incidences=part.num_incidences, inc_counted=part.inc_counted,
+                       edge_counted=part.edge_counted, nx_global=part.nx_global, nmu_global=part.nmu_global, **kw)
+    uid = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = dist.get_backend(group)
+        tdev = dev.device if backend == "nccl" else torch.device("cpu")
+        t = torch.zeros(128, dtype=torch.uint8, device=tdev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(dev.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, src=0, group=group)
+        uid = bytes(t.cpu().numpy().tobytes())
+    dev.attach_comm(rank, world, uid, part.send_idx, part.recv_idx)
+    return part, dev

@@ -26,6 +26,9 @@ STATUS_NAME = {RUNNING: "running", CONVERGED: "converged", MAX_IT: "max_it", DIV
 EXPORTS = ["gcsadmm_create", "gcsadmm_destroy", "gcsadmm_last_error", "gcsadmm_reset", "gcsadmm_vertex_step",
            "gcsadmm_edge_step", "gcsadmm_control", "gcsadmm_run", "gcsadmm_run_timed", "gcsadmm_read_control",
            "gcsadmm_cost", "gcsadmm_query",
+           # vertex partitions across GPUs (RCCL)
+           "gcsadmm_comm_unique_id", "gcsadmm_attach_comm", "gcsadmm_run_partitioned", "gcsadmm_halo_pack", "gcsadmm_halo_unpack",
+           "gcsadmm_halo_exchange", "gcsadmm_halo_buffers",
            # graph construction at scale (gcs_admm_amd/scene.py)
            "gcsadmm_polytope_last_error", "gcsadmm_polytope_centers", "gcsadmm_polytope_bounds", "gcsadmm_polytope_overlaps"]
 
@@ -52,6 +55,26 @@ class Params(C.Structure):
 class State(C.Structure):
     _fields_ = [("copy", C.c_void_p), ("mu", C.c_void_p), ("zedge", C.c_void_p),
                 ("xv", C.c_void_p), ("zv", C.c_void_p), ("yv", C.c_void_p)]
+
+
+class HaloDesc(C.Structure):
+    _fields_ = [("num_peers", C.c_int32), ("peer_rank", C.c_void_p), ("send_ptr", C.c_void_p), ("send_cols", C.c_void_p),
+                ("recv_ptr", C.c_void_p), ("recv_cols", C.c_void_p)]
+
+
+def halo_arrays(send_idx, recv_idx):
+    """The halo lists of a vertex partition (gcs_admm_amd.partition.LocalPartition.send_idx / recv_idx: neighbour rank ->
+    columns in canonical (global edge, side) order) as the flat CSR arrays of ``gcsadmm_halo_desc``: peers in ascending
+    rank order, send and receive lists of a peer equally long.  Returns (peer_rank, ptr, send_cols, recv_cols) int32."""
+    peers = sorted(send_idx)
+    if sorted(recv_idx) != peers:
+        raise ValueError("a partition sends to and receives from the same neighbours")
+    cnt = [len(send_idx[r]) for r in peers]
+    if cnt != [len(recv_idx[r]) for r in peers]:
+        raise ValueError("send and receive lists of a neighbour must be equally long")
+    ptr = np.zeros(len(peers) + 1, np.int32); ptr[1:] = np.cumsum(cnt)
+    cat = lambda d: (np.concatenate([np.asarray(d[r], np.int32) for r in peers]) if peers else np.zeros(0, np.int32))
+    return np.asarray(peers, np.int32), ptr, np.ascontiguousarray(cat(send_idx)), np.ascontiguousarray(cat(recv_idx))
 
 
 class ControlBlock(C.Structure):
@@ -206,6 +229,58 @@ class DeviceSolver:
                                                self._stream(), C.byref(vm), C.byref(vl), C.byref(em), C.byref(el)),
                     "gcsadmm_run_timed")
         return dict(vertex_ms=vm.value, vertex_launches=vl.value, edge_ms=em.value, edge_launches=el.value)
+
+    # ---- vertex partition across GPUs -------------------------------------------------
+    def unique_id(self) -> bytes:
+        """128 bytes naming a new RCCL communicator (rank 0 creates it, the host distributes it)"""
+        buf = (C.c_ubyte * 128)()
+        st = self.lib.gcsadmm_comm_unique_id(buf)
+        if st != 0:
+            raise GcsAdmmError(f"gcsadmm_comm_unique_id failed ({st}): {self.lib.gcsadmm_last_error(None).decode()}")
+        return bytes(buf)
+
+    def attach_comm(self, rank: int, world: int, unique_id, send_idx, recv_idx):
+        """Join the communicator (collective) and upload this partition's halo lists.  ``unique_id`` None: world 1 only."""
+        peers, ptr, sc, rc = halo_arrays(send_idx, recv_idx)
+        self._halo_keep = (peers, ptr, sc, rc)
+        hd = HaloDesc(len(peers), _np_ptr(peers), _np_ptr(ptr), _np_ptr(sc), _np_ptr(ptr), _np_ptr(rc))
+        idb = (C.c_ubyte * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        with self.torch.cuda.device(self.device):
+            self._check(self.lib.gcsadmm_attach_comm(self.h, int(rank), int(world), idb, C.byref(hd)), "gcsadmm_attach_comm")
+
+    def enqueue_partitioned(self, k: int):
+        """k iterations of the partitioned loop back to back on the current stream (every rank enqueues the same k)"""
+        self._check(self.lib.gcsadmm_run_partitioned(self.h, C.byref(self.state), int(k), C.c_void_p(self.trace.data_ptr()),
+                                                     self._stream()), "gcsadmm_run_partitioned")
+
+    def halo_pack(self):
+        self._check(self.lib.gcsadmm_halo_pack(self.h, C.byref(self.state), self._stream()), "gcsadmm_halo_pack")
+
+    def halo_unpack(self):
+        self._check(self.lib.gcsadmm_halo_unpack(self.h, C.byref(self.state), self._stream()), "gcsadmm_halo_unpack")
+
+    def halo_exchange(self):
+        self._check(self.lib.gcsadmm_halo_exchange(self.h, C.byref(self.state), self._stream()), "gcsadmm_halo_exchange")
+
+    def halo_buffers(self):
+        """(send pointer, receive pointer, elements) of the packed halo buffers (device memory owned by the handle)"""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        self._check(self.lib.gcsadmm_halo_buffers(self.h, C.byref(a), C.byref(b), C.byref(n)), "gcsadmm_halo_buffers")
+        return a.value, b.value, n.value
+
+    def solve_partitioned(self, chunk: int = 25, **params):
+        """The partitioned loop to its stop test: as ``solve`` but through gcsadmm_run_partitioned (collective)."""
+        self.reset(**params)
+        max_it = self.params.max_it
+        done = 0
+        while True:
+            k = min(chunk, max_it - done)
+            if k > 0:
+                self.enqueue_partitioned(k)
+                done += k
+            cb = self.read_control()
+            if cb.status != RUNNING or done >= max_it:
+                return cb
 
     def read_control(self) -> ControlBlock:
         cb = ControlBlock()

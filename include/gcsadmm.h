@@ -171,6 +171,42 @@ gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int3
                                  float *edge_ms, int32_t *edge_launches);
 
 /* ---------------------------------------------------------------------------------------------
+ * Vertex partitions across GPUs.  The reference's fan-out point is admm_solver_v3.py:490
+ * (SolveInParallel over all vertices); here each rank holds one handle built from its part of the graph (ghost incidence
+ * columns for the remote endpoint of every cut edge, ownership masks, global nx / nmu: see gcsadmm_graph_desc) and the ranks
+ * meet twice per iteration: the halo exchange of the cut edges' copies and one all-reduce of six doubles.  Both run on the
+ * caller's stream through RCCL (bound at run time with dlopen: the library has no link dependency on it).
+ */
+typedef struct gcsadmm_halo_desc {
+    int32_t num_peers;               /* neighbour partitions (<= 2 for strip partitions) */
+    const int32_t *peer_rank;        /* [num_peers] */
+    const int32_t *send_ptr;         /* [num_peers+1] CSR into send_cols */
+    const int32_t *send_cols;        /* owned incidence columns whose copies go to that peer, in (global edge, side) order */
+    const int32_t *recv_ptr;         /* [num_peers+1] CSR into recv_cols; recv_ptr == send_ptr entry by entry */
+    const int32_t *recv_cols;        /* ghost columns filled from that peer, same canonical order */
+} gcsadmm_halo_desc;
+
+/* 128 bytes identifying a new communicator (ncclGetUniqueId); rank 0 calls it, the host distributes the bytes (any transport). */
+gcsadmm_status gcsadmm_comm_unique_id(void *id128);
+
+/* Attach rank `rank` of `world` to the communicator `id128` (collective: every rank calls it; blocks until all have) and
+ * upload the halo lists.  id128 == NULL: no communicator is created -- for world == 1 the exchange and the all-reduce are
+ * no-ops; for world > 1 the host moves the packed halo itself (gcsadmm_halo_pack / _buffers / _unpack) and drives the steps. */
+gcsadmm_status gcsadmm_attach_comm(gcsadmm_handle h, int32_t rank, int32_t world, const void *id128, const gcsadmm_halo_desc *halo);
+
+/* Enqueue up to k full iterations of the partitioned loop (vertex step, halo exchange, edge step, all-reduce, control) with
+ * no host synchronisation; every rank must enqueue the same k.  trace_dev as for gcsadmm_run (identical on every rank). */
+gcsadmm_status gcsadmm_run_partitioned(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream);
+
+/* The pieces of the halo exchange, for hosts that bring their own transport and for tests: pack the copies to send into the
+ * send buffer ([c][columns of peer] per peer, in peer order) / scatter the receive buffer into the ghost columns / both with
+ * the RCCL transfer in between / the two device buffers and their length in elements of the state type. */
+gcsadmm_status gcsadmm_halo_pack(gcsadmm_handle h, const gcsadmm_state *st, void *stream);
+gcsadmm_status gcsadmm_halo_unpack(gcsadmm_handle h, const gcsadmm_state *st, void *stream);
+gcsadmm_status gcsadmm_halo_exchange(gcsadmm_handle h, const gcsadmm_state *st, void *stream);
+gcsadmm_status gcsadmm_halo_buffers(gcsadmm_handle h, void **send_buf, void **recv_buf, int64_t *num_elements);
+
+/* ---------------------------------------------------------------------------------------------
  * Graph construction at scale.  The reference decides every ordered pair of
  * regions with one LP feasibility solve through Drake/MOSEK (utils.py:31-82 build_graph, :49-65
  * check_overlap); these entry points run the same decisions as batches of tiny LPs on the device, one LP

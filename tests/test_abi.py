@@ -31,7 +31,7 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     from gcs_admm_amd import solver
     pairs = [("gcsadmm_graph_desc", solver.GraphDesc), ("gcsadmm_params", solver.Params), ("gcsadmm_state", solver.State),
-             ("gcsadmm_control_block", solver.ControlBlock)]
+             ("gcsadmm_control_block", solver.ControlBlock), ("gcsadmm_halo_desc", solver.HaloDesc)]
     lines = []
     for cname, ct in pairs:
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -217,3 +217,65 @@ def test_terminal_with_extent_is_refused(torch_gpu):
     g = graph_from_sets(As, bs, 2)
     with pytest.raises(solver.GcsAdmmError, match="point"):
         _solver(g)
+
+
+def test_partitioned_loop_behind_the_abi_single_rank(torch_gpu):
+    """gcsadmm_run_partitioned with a REAL RCCL communicator of one rank (what a one-GPU box can exercise: run-time binding
+    of librccl, communicator creation, the 6-double all-reduce on the caller's stream, the control step fed from it):
+    the trace equals the single-handle loop's bit for bit."""
+    from gcs_admm_amd.solver import DeviceSolver
+    g = lattice_boxes(20, 18, seed=2)
+    a = DeviceSolver(g, "f64", device=0)
+    a.reset(max_it=40)
+    a.enqueue(30)
+    b = DeviceSolver(g, "f64", device=0)
+    b.attach_comm(0, 1, b.unique_id(), {}, {})
+    b.reset(max_it=40)
+    b.enqueue_partitioned(30)
+    ca, cb = a.read_control(), b.read_control()
+    assert ca.it == cb.it == 31 and ca.status == cb.status and cb.inner_failures == 0
+    assert np.array_equal(a.trace[:30].cpu().numpy(), b.trace[:30].cpu().numpy())
+    assert np.array_equal(a.zedge.cpu().numpy(), b.zedge.cpu().numpy())
+
+
+def test_halo_pack_unpack_two_handles(torch_gpu):
+    """the pack / unpack kernels and halo lists of the C ABI with the transfer done by hand: two partitions of one lattice
+    as two handles on this GPU; packed send buffers are copied device-to-device into the peer's receive buffer (what
+    ncclSend / ncclRecv do across GPUs), then unpacked into the ghost columns.  Against the single handle."""
+    torch = torch_gpu
+    import ctypes as C
+    import os
+    from gcs_admm_amd.partition import build_partition, strip_owner
+    from gcs_admm_amd.solver import DeviceSolver
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    g = lattice_boxes(12, 16, seed=5)
+    single = DeviceSolver(g, "f32", device=0)
+    single.reset(max_it=60)
+    owner = strip_owner(g, 2)
+    parts = [build_partition(g, owner, r, 2) for r in range(2)]
+    devs = [DeviceSolver(p.graph, "f32", device=0, num_incidences=p.num_incidences, inc_counted=p.inc_counted,
+                         edge_counted=p.edge_counted, nx_global=p.nx_global, nmu_global=p.nmu_global) for p in parts]
+    for r, (p, d) in enumerate(zip(parts, devs)):
+        d.attach_comm(r, 2, None, p.send_idx, p.recv_idx)
+        d.reset(max_it=60)
+    bufs = [d.halo_buffers() for d in devs]
+    assert bufs[0][2] == bufs[1][2] == g.c * len(parts[0].send_idx[1])
+    for it in range(25):
+        single.vertex_step(); s_ref = single.edge_step().clone(); single.control()
+        for d in devs:
+            d.vertex_step(); d.halo_pack()
+        torch.cuda.synchronize()
+        for r in range(2):
+            assert hip.hipMemcpy(C.c_void_p(bufs[r][1]), C.c_void_p(bufs[1 - r][0]), C.c_size_t(4 * bufs[r][2]), 3) == 0   # DeviceToDevice
+        tot = torch.zeros(5, dtype=torch.float64, device="cuda")
+        for d in devs:
+            d.halo_unpack()
+            tot += d.edge_step()
+        assert torch.allclose(tot, s_ref, rtol=1e-3, atol=1e-9)
+        for d in devs:
+            d.control(tot)
+    full = single.zedge.cpu().numpy()
+    for p, d in zip(parts, devs):
+        assert np.allclose(d.zedge.cpu().numpy(), full[:, p.edge_global], rtol=0, atol=5e-4)
+    cbs = [d.read_control() for d in devs] + [single.read_control()]
+    assert len({cb.it for cb in cbs}) == 1 and len({cb.status for cb in cbs}) == 1

@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from gcs_admm_amd.cases import load_fixture
 from gcs_admm_amd.graph import lattice_boxes, graph_from_sets
+from gcs_admm_amd import solver as _solver_mod
+if os.environ.get('GCSADMM_PROBE_LIB'):
+    _solver_mod.LIB_PATH = os.path.abspath(os.environ['GCSADMM_PROBE_LIB'])   # development: probe an experimental build
 from gcs_admm_amd.solver import DeviceSolver
 from oracle.oracle import Oracle
 
@@ -59,6 +62,13 @@ if "rate" in which:
         g = lattice_boxes(nx, ny, seed=0)
         for prog in ("workgroup", "wavefront"):
             rate(f"lat{nx}x{ny}", g, prog, "f32", steps=60, warm=5)
+if "small" in which:
+    case, g4 = load_fixture("benchmark4")
+    rate("benchmark4", g4, "workgroup", "f64", steps=300, warm=20)
+    for nm in ("benchmark3", "benchmark1"):
+        rate(nm, load_fixture(nm)[1], "workgroup", "f64", steps=300, warm=20)
+    for (nx, ny) in ((16, 16), (24, 24), (32, 32)):
+        rate(f"lat{nx}x{ny}", lattice_boxes(nx, ny, seed=0), "workgroup", "f32", steps=100, warm=5)
 if "s6d" in which:
     g = lattice_boxes(223, 224, n=6, seed=0)
     rate("s6d", g, "workgroup", "f32", steps=10, warm=2)
@@ -67,4 +77,4 @@ if "s6d" in which:
     g = lattice_boxes(60, 60, n=3, seed=0)
     rate("lat3_60x60", g, "workgroup", "f32", steps=20, warm=2)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "wg_probe_" + "_".join(which) + ".json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "wg_probe_" + "_".join(which) + os.environ.get("GCSADMM_PROBE_TAG", "") + ".json"), "w"), indent=1)
