@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py -- ADMM iterations/sec of the MI355X loop on the configuration BASELINE.json quotes its
-metric on (benchmark4, f64, reference stop rule), one JSON line on stdout.
+"""bench.py -- ADMM iterations/sec of the MI355X loop on the configuration BASELINE.json quotes its metric on
+(benchmark4, f64, reference stop rule), one JSON line on stdout.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload benchmark4|s10k]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload benchmark4|s10k|s100k|s6d]
 
-A "step" is one full ADMM iteration (vertex step, edge step, control) on the resident state; K steps
-are enqueued back to back (no host round trip) between two synchronisation points.  The state is
-already in HBM when the timed region starts.  `roofline` prices the dominant kernel (vertex step)
-with the algorithmic bytes of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle
-(oracle/gcs_oracle.c, "port") on the same workload on the host cores of the GPU box.
+A "step" is one full ADMM iteration (vertex step, edge step, control) on the resident state; K steps are enqueued back
+to back (no host round trip) between two synchronisation points.  The state is already in HBM when the timed region
+starts.  `roofline` prices the dominant kernel (vertex step) with the algorithmic bytes of SURVEY.md section 8(d);
+`cpu_baseline` times the CPU oracle (oracle/gcs_oracle.c, "port") on the same workload on the host cores of the GPU box.
+
+Multi-GPU (--gpus N, launched with torch.distributed.run): benchmark4 has 42 vertices and does not shard, so the headline
+`value` is the throughput of N independent replicas (labelled as such -- it says nothing about the sharded path).  The
+SHARDED path is measured beside it in `partitioned_s100k`: BASELINE config 4, one 316 x 317 lattice in N row strips, the
+loop entirely behind the C ABI (gcsadmm_run_partitioned: RCCL halo exchange + 6-double all-reduce on one stream),
+strong scaling against the same lattice on one GPU measured in the same run.
 """
 import argparse
 import json
@@ -20,10 +25,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+F64_VECTOR_PEAK_TF = 78.6      # MI355X f64 vector peak (spec)
 REF_PUBLISHED_ITS = 465 / 37.87852382659912   # v3 / benchmark4, solver-time-only, hardware unknown
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
-def make_workload(name, rank=0, world=1):
+def make_workload(name):
     from gcs_admm_amd.cases import load_fixture
     from gcs_admm_amd.graph import lattice_boxes
     if name == "benchmark4":
@@ -38,15 +45,53 @@ def make_workload(name, rank=0, world=1):
     raise SystemExit(f"unknown workload {name}")
 
 
-def time_loop(dev, steps, warmup, params):
+def time_loop(dev, steps, warmup, params, enqueue=None):
     import torch
+    enqueue = enqueue or dev.enqueue
     dev.reset(**params)
-    dev.enqueue(warmup)
+    enqueue(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dev.enqueue(steps)
+    enqueue(steps)
     torch.cuda.synchronize()
     return time.perf_counter() - t0
+
+
+def cpu_baseline(g, workload, seconds=20.0):
+    """the oracle on the host cores: best thread count of a short sweep, then a bounded sample at that count"""
+    from oracle.oracle import Oracle
+    ncpu = os.cpu_count() or 1
+    n_probe = 20 if workload == "benchmark4" else 2
+    best, cores = 0.0, 1
+    for th in sorted({1, 8, 16, 32, 64, 128, ncpu}):
+        if th > ncpu or (th == 1 and g.num_vertices > 5000 and ncpu > 1):
+            continue
+        o = Oracle(g, ipm_tol=1e-9)
+        t0 = time.perf_counter()
+        o.run(max_it=n_probe, eps_abs=0.0, eps_rel=0.0, nthreads=th)
+        r = n_probe / (time.perf_counter() - t0)
+        if r > best:
+            best, cores = r, th
+    n_it = max(n_probe, int(min(seconds * best, 2000)))
+    o = Oracle(g, ipm_tol=1e-9)
+    t0 = time.perf_counter()
+    o.run(max_it=n_it, eps_abs=0.0, eps_rel=0.0, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n_it / dt, "unit": "iterations/s", "cores": cores, "kind": "port", "host_cpus": ncpu,
+            "sample": f"{n_it} iterations of the same workload from the zero state (oracle/gcs_oracle.c, OpenMP over vertices, "
+                      f"best thread count of a sweep up to {ncpu})"}
+
+
+def counted_flops(g):
+    """f64 operations of ONE vertex step from the zero state, counted (not modelled): the workgroup program's source
+    compiled for the host with a counting scalar type (tools/flopcount), add / mul = 1, fma = 2, division and square root
+    listed apart.  None when the counter is not built."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools", "flopcount"))
+        import wg_flops
+        return wg_flops.count_vertex_step(g)
+    except Exception:      # tooling, never the product: its absence only drops the field
+        return None
 
 
 def main():
@@ -55,6 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="benchmark4", choices=["benchmark4", "s10k", "s100k", "s6d"])
+    ap.add_argument("--program", default="auto", choices=["auto", "wavefront", "workgroup"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--loop-only", action="store_true",
                     help="only the timed loop and the per-kernel timing (no convergence runs, no CPU baseline): the "
@@ -70,8 +116,10 @@ def main():
         dist.init_process_group("nccl")
     from gcs_admm_amd.solver import DeviceSolver
 
-    g, dtype, extra = make_workload(args.workload, rank, world)
-    dev = DeviceSolver(g, dtype, device=local)
+    g, dtype, extra = make_workload(args.workload)
+    dev = DeviceSolver(g, dtype, device=local, program=args.program)
+    q = dev.query()
+    program = "workgroup" if q["num_workgroup_vertices"] and not q["num_waves"] else ("wavefront" if not q["num_workgroup_vertices"] else "mixed")
     # fixed-length timing window: the stop test is disabled (eps = 0) so that exactly K iterations run
     params = dict(max_it=args.steps + args.warmup + 1, eps_abs=0.0, eps_rel=0.0)
     if world > 1:
@@ -83,18 +131,24 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    its = args.steps / el * world     # N independent replicas of the workload
+    its = args.steps / el * world     # N independent replicas of the workload when N > 1 (it does not shard)
 
     out = {"metric": "admm_iterations_per_sec", "value": its, "unit": "iterations/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": its / REF_PUBLISHED_ITS if args.workload == "benchmark4" else None,
-           "dtype": "f64", "data": "synthetic" if args.workload != "benchmark4" else "fixture of the reference's test_data/benchmark4.py",
+           "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": its / REF_PUBLISHED_ITS if (args.workload == "benchmark4" and world == 1) else None,
+           "dtype": "f64" if dtype == "f64" else "f64 (interior point) on f32 state",
+           "data": "synthetic" if args.workload != "benchmark4" else "fixture of the reference's test_data/benchmark4.py",
            "config": {"workload": args.workload, "V": g.num_vertices, "E": g.num_edges, "n": g.n,
-                      "state_dtype": dtype, "inner_arithmetic": "f64", "ipm_tol": 1e-9,
-                      "parallelism": f"{world} replica(s)",
+                      "state_dtype": dtype, "inner_arithmetic": "f64", "ipm_tol": 1e-9, "vertex_program": program,
+                      "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (the workload does not shard; "
+                                                                  "the sharded path is in partitioned_s100k)",
                       "seed": None if args.workload == "benchmark4" else 0,
                       "degree_histogram": {int(k): int(v) for k, v in zip(*np.unique(np.diff(g.inc_ptr), return_counts=True))},
                       "facets_histogram": {int(k): int(v) for k, v in zip(*np.unique(np.diff(g.poly_ptr), return_counts=True))}}}
+    if world > 1:
+        out["value_note"] = ("throughput of N independent instances of the 42-vertex benchmark4 (no collective): not a scaling "
+                             "result; scaling of the sharded path: partitioned_s100k.speedup_vs_1gpu")
     if rank == 0:
         # ---- roofline of the dominant kernel (vertex step), measured with HIP events on its stream ----
         dev.reset(**params)
@@ -105,112 +159,106 @@ def main():
         wb = 8 if dtype == "f64" else 4
         alg_bytes = g.algorithmic_bytes_per_iteration(wb)
         ach = alg_bytes / (v_ms * 1e-3) / 1e9
-        q = dev.query()
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01", "s10k_f32state_hbm_counters_v10.json")
-        if args.workload == "s10k" and os.path.exists(prof):
-            # PMC counters cannot be read from inside this process: the per-launch figure is the one rocprofv3
-            # collected for this same command line (separate --pmc passes, profiles/r01), FETCH_SIZE doubled
-            # as MI355X_MICROARCH.md prescribes for gfx950, KB -> bytes
+        kernel = {"workgroup": f"vertex_wg_kernel<{g.n}>", "wavefront": "vertex_kernel<2>", "mixed": "vertex_kernel<2> + vertex_wg_kernel<2>"}[program]
+        traffic, traffic_src = None, None
+        prof = os.path.join(PROFILE_DIR, f"{args.workload}_hbm_counters.json")
+        if os.path.exists(prof):
+            # PMC counters cannot be read from inside this process: the per-launch figure is the one rocprofv3 collected for
+            # this same command line (separate --pmc passes, profiles/r02), FETCH_SIZE doubled as MI355X_MICROARCH.md
+            # prescribes for gfx950, KB -> bytes
             pc = json.load(open(prof))
-            traffic = 1024.0 * (2.0 * pc["FETCH_SIZE"]["vertex_kernel"]["mean_KB_per_launch"]
-                                + pc["WRITE_SIZE"]["vertex_kernel"]["mean_KB_per_launch"])
-        # model flops of one Newton iteration of one vertex (f64 flops, FMA = 2; analytic count of the kernel's
-        # arithmetic, not a hardware counter): facet-row passes 4 x ~52(n/2+1) per row pair, block algebra
-        # ~(2n+1)^3 * 10, border algebra ~(4n+1)^3 * 5.5
-        n_, cb_ = g.n, dev.read_control()
-        deg = np.diff(g.inc_ptr); mfac = np.diff(g.poly_ptr)
-        gen = np.ones(g.num_vertices, bool); gen[[g.src, g.dst]] = False
-        per_vertex = (deg + 1) * 2 * mfac * 210.0 * (n_ / 2.0) + deg * 10.0 * (2 * n_ + 1) ** 3 + 5.5 * (4 * n_ + 1) ** 3
-        it_per_vertex = cb_.inner_iters / max(int(gen.sum()), 1)
-        flops = float(per_vertex[gen].sum()) * it_per_vertex
-        out["roofline_fp"] = {"bound": "f64 vector", "achieved": flops / (v_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                              "frac": flops / (v_ms * 1e-3) / 1e12 / 78.6, "note": "model flops (analytic count), per vertex-step launch",
-                              "newton_iterations_per_vertex": it_per_vertex}
+            kk = next((k for k in pc.get("FETCH_SIZE", {}) if k.startswith("vertex")), None)
+            if kk and kk in pc.get("WRITE_SIZE", {}):
+                traffic = 1024.0 * (2.0 * pc["FETCH_SIZE"][kk]["mean_KB_per_launch"] + pc["WRITE_SIZE"][kk]["mean_KB_per_launch"])
+                traffic_src = os.path.relpath(prof, ROOT)
+        cb_ = dev.read_control()
+        n_generic = g.num_vertices - q["num_special"]
+        it_per_vertex = cb_.inner_iters / max(n_generic, 1)
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": "vertex_kernel<2>", "avg_launch_ms": v_ms,
+                           "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "avg_launch_ms": v_ms,
                            "algorithmic_bytes_per_launch": alg_bytes, "edge_step_avg_ms": e_ms,
                            "waves": q["num_waves"], "lds_bytes_per_wave": q["lds_bytes"],
-                           "inner_iters_last_step_total": dev.read_control().inner_iters,
-                           "special_vertices": q["num_special"]}
+                           "workgroup_vertices": q["num_workgroup_vertices"], "lds_bytes_per_workgroup": q["workgroup_lds_bytes"],
+                           "newton_iterations_per_vertex": it_per_vertex, "special_vertices": q["num_special"],
+                           "note": "the vertex step is bound by dependent f64 issue / LDS latency, not by HBM (DESIGN.md section 4): "
+                                   "the HBM fraction on algorithmic bytes is reported as SURVEY 8(d) asks; see roofline_fp"}
+        fl = None if args.loop_only else counted_flops(g)
+        if fl is not None:
+            # the count is of the first vertex step (zero state); later steps take the same number of Newton iterations +-1
+            scale = it_per_vertex / max(fl["newton_iterations_per_vertex"], 1e-9)
+            flops = fl["flops"] * scale
+            out["roofline_fp"] = {"bound": "f64 vector", "achieved": flops / (v_ms * 1e-3) / 1e12, "peak": F64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": flops / (v_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TF, "flops_per_launch": flops,
+                                  "divisions_per_launch": fl["div"] * scale, "sqrt_per_launch": fl["sqrt"] * scale,
+                                  "note": "COUNTED f64 operations of the vertex step (tools/flopcount: the workgroup program's source "
+                                          "compiled for the host with a counting scalar; add/mul = 1, fma = 2), scaled to this "
+                                          "window's Newton iterations per vertex"}
         # the streaming half of the iteration on its own (edge average + dual + residual sums + control,
         # 14 c |E| words), HBM-bound once the state outgrows the caches
         edge_bytes = 14.0 * g.c * g.num_edges * wb
         out["roofline_edge"] = {"bound": "hbm", "achieved": edge_bytes / (e_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": edge_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "edge_kernel+finalize+control",
+                                "frac": edge_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "edge_kernel (+finalize/control)",
                                 "avg_step_ms": e_ms, "algorithmic_bytes_per_step": edge_bytes}
         # ---- matched convergence: the reference's own stop rule ----
         if args.workload == "benchmark4" and not args.loop_only:
-            res = dev.solve()
+            res = dev.solve(timed=True)
             gold = extra["case"]["golden_v3"]
             out["convergence"] = {"iterations_to_stop": res["iterations"], "reference_iterations": gold["iterations"],
                                   "cost": res["cost"], "reference_cost": gold["cost"],
-                                  "classic_cost": extra["case"]["golden_classic"]["cost"]}
+                                  "classic_cost": extra["case"]["golden_classic"]["cost"],
+                                  "solve_time_s": res["device_time_s"], "loop_wall_time_s": res["wall_time_s"],
+                                  "reference_solve_time_s": gold["solve_time"]}
             # iterations-to-eps (the second half of BASELINE.json's metric): eps_abs = eps_rel = 1e-6, MAX_IT lifted;
             # the relaxation optimum the monolithic solve reports (classic_solver record) is the yardstick
             tight = dev.solve(chunk=500, max_it=40000, eps_abs=1e-6, eps_rel=1e-6)
             classic = extra["case"]["golden_classic"]["cost"]
             out["iters_to_eps"] = {"eps_abs": 1e-6, "eps_rel": 1e-6, "iterations": tight["iterations"], "status": tight["status"],
-                                   "cost": tight["cost"], "rel_gap_to_classic": abs(tight["cost"] - classic) / classic}
+                                   "cost": tight["cost"], "rel_gap_to_classic": abs(tight["cost"] - classic) / classic,
+                                   "wall_time_s": tight["wall_time_s"]}
             out["reference_published"] = {"its_per_sec": REF_PUBLISHED_ITS, "note": "465 it / 37.88 s solver-time-only, hardware unknown (BASELINE.md)"}
         # ---- CPU baseline: the oracle on the host cores, bounded sample ----
         if not args.no_cpu and not args.loop_only and world == 1:
-            from oracle.oracle import Oracle
-            ncpu = os.cpu_count() or 1
-            # thread count: the best of a short sweep (OpenMP over vertices; more threads than vertices, or
-            # than memory channels can feed, only costs fork/join time), then the bounded sample at that count
-            n_probe = 20 if args.workload == "benchmark4" else 2
-            best, cores = 0.0, 1
-            for th in sorted({1, 8, 16, 32, 64, 128, ncpu}):
-                if th > ncpu or (th == 1 and g.num_vertices > 5000 and ncpu > 1):
-                    continue
-                o = Oracle(g, ipm_tol=1e-9)
-                t0 = time.perf_counter()
-                o.run(max_it=n_probe, eps_abs=0.0, eps_rel=0.0, nthreads=th)
-                r = n_probe / (time.perf_counter() - t0)
-                if r > best:
-                    best, cores = r, th
-            n_it = max(n_probe, int(min(20.0 * best, 2000)))      # ~20 s of CPU work
-            o = Oracle(g, ipm_tol=1e-9)
-            t0 = time.perf_counter()
-            o.run(max_it=n_it, eps_abs=0.0, eps_rel=0.0, nthreads=cores)
-            dt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": n_it / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
-                                   "host_cpus": ncpu,
-                                   "sample": f"{n_it} iterations of the same workload from the zero state (oracle/gcs_oracle.c, "
-                                             f"OpenMP over vertices, best thread count of a sweep up to {ncpu})"}
-    if world > 1:
-        # ---- the partitioned path (real halo exchange + all-reduce over RCCL): one lattice of ~10k vertices
-        #      per GPU, row strips; reported beside the headline (which uses independent replicas because the
-        #      42-vertex benchmark4 does not shard) ----
+            out["cpu_baseline"] = cpu_baseline(g, args.workload)
+    # ---- the sharded path: BASELINE config 4, strong scaling, everything behind the C ABI ----
+    if (world > 1 or args.workload == "benchmark4") and not args.loop_only:
+        block, ok = {}, 1.0
         try:
             from gcs_admm_amd.graph import lattice_boxes
-            from gcs_admm_amd.partition import PartitionedLoop, build_partition, strip_owner
-            gl = lattice_boxes(100, 100 * world, seed=0)
-            part = build_partition(gl, strip_owner(gl, world), rank, world)
-            pdev = DeviceSolver(part.graph, "f32", device=local, num_incidences=part.num_incidences,
-                                inc_counted=part.inc_counted, edge_counted=part.edge_counted,
-                                nx_global=part.nx_global, nmu_global=part.nmu_global)
+            from gcs_admm_amd.partition import device_partition
+            gl = lattice_boxes(316, 317, seed=0)
             psteps, pwarm = min(args.steps, 100), min(args.warmup, 10)
-            pdev.reset(max_it=psteps + pwarm + 1, eps_abs=0.0, eps_rel=0.0)
-            loop = PartitionedLoop(part, pdev)
-            loop.iterate(pwarm)
-            torch.cuda.synchronize(); dist.barrier()
-            t0 = time.perf_counter()
-            loop.iterate(psteps)
-            torch.cuda.synchronize(); dist.barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            halo = torch.tensor([sum(len(v) for v in part.send_idx.values())], dtype=torch.float64, device="cuda")
-            dist.all_reduce(halo)
+            pparams = dict(max_it=psteps + pwarm + 1, eps_abs=0.0, eps_rel=0.0)
+            part, pdev = device_partition(gl, rank, world, "f32", device=local)
+        except Exception as exc:
+            ok, block = 0.0, {"error": f"rank {rank}: {type(exc).__name__}: {exc}"}
+        if world > 1:      # every rank learns whether ALL ranks are ready before the first collective of this leg
+            flag = torch.tensor([ok], dtype=torch.float64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = float(flag.item())
+        if ok:
+            if world > 1:
+                dist.barrier()
+            pel = time_loop(pdev, psteps, pwarm, pparams, enqueue=pdev.enqueue_partitioned)
+            pcb = pdev.read_control()
+            halo = float(sum(len(v) for v in part.send_idx.values()))
+            if world > 1:
+                t = torch.tensor([pel, halo], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t[:1], op=dist.ReduceOp.MAX); dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+                pel, halo = float(t[0].item()), float(t[1].item())
             if rank == 0:
-                out["partitioned_lattice"] = {"V": gl.num_vertices, "E": gl.num_edges, "vertices_per_gpu": gl.num_vertices / world,
-                                              "iterations_per_sec": psteps / float(t.item()), "ms_per_iteration": 1e3 * float(t.item()) / psteps,
-                                              "halo_columns_per_iteration": int(halo.item()), "collectives_per_iteration": "1 p2p batch + 1 all-reduce(5 f64)",
-                                              "state_dtype": "f32", "scaling": "weak (10k vertices per GPU, row strips)"}
-        except Exception as exc:   # the headline line must survive a failure of this extra leg
-            if rank == 0:
-                out["partitioned_lattice"] = {"error": f"{type(exc).__name__}: {exc}"}
+                block = {"workload": "s100k (316 x 317 box lattice, BASELINE config 4)", "V": gl.num_vertices, "E": gl.num_edges,
+                         "partition": f"{world} row strip(s), one per GPU", "state_dtype": "f32", "scaling": "strong",
+                         "iterations_per_sec": psteps / pel, "ms_per_iteration": 1e3 * pel / psteps, "iterations": int(pcb.it) - 1,
+                         "halo_columns_per_iteration": int(halo), "halo_bytes_per_iteration": int(halo) * gl.c * 4,
+                         "collectives_per_iteration": "1 grouped send/recv per neighbour + 1 all-reduce of 6 f64",
+                         "path": "gcsadmm_run_partitioned (C ABI, RCCL on the caller's stream, no host synchronisation)"}
+                if world > 1:      # the same lattice on one GPU, same loop: the strong-scaling reference
+                    sdev = DeviceSolver(gl, "f32", device=local)
+                    sel = time_loop(sdev, psteps, pwarm, pparams)
+                    block["single_gpu_iterations_per_sec"] = psteps / sel
+                    block["speedup_vs_1gpu"] = sel / pel
+        if rank == 0:
+            out["partitioned_s100k"] = block
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

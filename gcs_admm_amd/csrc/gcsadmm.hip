@@ -1,14 +1,15 @@
 // gcsadmm.hip -- gfx950 kernels and C ABI (include/gcsadmm.h) of the ADMM iteration loop.
 //
 // Kernels (one HIP stream, launched back to back, no host round trip inside the loop):
-//   vertex_kernel<N,T>   x-update, generic vertices: one wavefront per workgroup, several vertices per
-//                        wavefront, program in vertex_program.h          (admm_solver_v3.py:352-540)
-//                        trailing workgroups of the same launch: x-update of s, t (closed form) and of vertices
-//                        no flow can cross (special_body)
-//   edge_kernel<T>       z-update, dual update, five partial norms        (admm_solver_v3.py:543-614)
+//   vertex_kernel<2,T>   x-update, wavefront program (n = 2, degree <= 63): one wavefront per workgroup, several vertices
+//                        per wavefront, program in vertex_program.h     (admm_solver_v3.py:352-540)
+//   vertex_wg_kernel<N,T> (vertex_wg.hip) x-update, workgroup program: one 256-thread workgroup per vertex, any n / degree
+//                        trailing workgroups of either launch: x-update of s, t (closed form) and of vertices no flow can cross
+//   edge_kernel<T,MODE,C> z-update, dual update, five partial norms     (admm_solver_v3.py:543-614); in gcsadmm_run the last
+//                        workgroup to finish also does the final reduction and the control step (one launch per edge step)
 //   finalize_kernel / control_kernel   deterministic final reduction; residuals, rho adaptation, stop test,
-//                        trace record (admm_solver_v3.py:697-733); gcsadmm_run uses the fused variants
-//                        (edge_kernel<T, true>, finalize_control_kernel): fewer launches per iteration
+//                        trace record (admm_solver_v3.py:697-733): the separate steps of the partitioned loop
+//   halo_pack / halo_unpack_kernel     messages of the cut edges' copies between vertex partitions (RCCL)
 //   cost_kernel<T>       GCS_utils.py:184-211
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -20,6 +21,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "gcsadmm.h"
@@ -114,11 +116,15 @@ __global__ void control_kernel(gcsadmm_control_block *cb, const double *sums, Co
     control_body(cb, sums, p, counters, trace, global_fails);
 }
 
-// FUSED (single workgroup, i.e. at most EDGE_BLOCK edges: gcsadmm_run on small graphs): the workgroup also does the
-// final reduction and the control step, which saves two ~4 us launches per iteration
-template <class T, bool FUSED>
+// MODE 0: partial sums per workgroup only (gcsadmm_edge_step: the caller all-reduces / finalizes);
+// MODE 1: single workgroup (at most EDGE_BLOCK edges, gcsadmm_run on small graphs): the workgroup also does the final
+//         reduction and the control step;
+// MODE 2: any grid (gcsadmm_run): the LAST workgroup to finish -- told by an agent-scope ticket counter -- reduces all the
+//         partials in the fixed order of finalize_kernel and runs the control step: one launch per edge step instead of two.
+// C = coupled words per copy (2n+1), compile-time so that all C x 5 loads of an edge are in flight at once.
+template <class T, int MODE, int C>
 __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm_control_block *cb, double *sums, ControlParams cp,
-                                                          int *counters, double *trace)
+                                                          int *counters, double *trace, unsigned *ticket)
 {
     if (cb->status != GCSADMM_RUNNING) return;
     const double mu_scale = cb->mu_scale;
@@ -128,14 +134,21 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
         const double we = a.edge_counted ? (double)a.edge_counted[e] : 1.0;
         const double wt = a.inc_counted ? (double)a.inc_counted[it] : 1.0;
         const double wh = a.inc_counted ? (double)a.inc_counted[ih] : 1.0;
-        for (int w = 0; w < a.c; ++w) {
-            const double cu = (double)a.copy[(size_t)w * a.NI + it], cw = (double)a.copy[(size_t)w * a.NI + ih];
-            const double zo = (double)a.zedge[(size_t)w * a.E + e];
+        T cu_[C], cw_[C], zo_[C], mu_[C], mw_[C];
+#pragma unroll
+        for (int w = 0; w < C; ++w) {
+            cu_[w] = a.copy[(size_t)w * a.NI + it]; cw_[w] = a.copy[(size_t)w * a.NI + ih];
+            zo_[w] = a.zedge[(size_t)w * a.E + e];
+            mu_[w] = a.mu[(size_t)w * a.NI + it]; mw_[w] = a.mu[(size_t)w * a.NI + ih];
+        }
+#pragma unroll
+        for (int w = 0; w < C; ++w) {
+            const double cu = (double)cu_[w], cw = (double)cw_[w], zo = (double)zo_[w];
             const T zn_t = (T)(0.5 * (cu + cw));
             const double zn = (double)zn_t;
             const double ru = cu - zn, rw = cw - zn;
-            const T mu_u_t = (T)(mu_scale * (double)a.mu[(size_t)w * a.NI + it] + ru);
-            const T mu_w_t = (T)(mu_scale * (double)a.mu[(size_t)w * a.NI + ih] + rw);
+            const T mu_u_t = (T)(mu_scale * (double)mu_[w] + ru);
+            const T mu_w_t = (T)(mu_scale * (double)mw_[w] + rw);
             a.mu[(size_t)w * a.NI + it] = mu_u_t;
             a.mu[(size_t)w * a.NI + ih] = mu_w_t;
             a.zedge[(size_t)w * a.E + e] = zn_t;
@@ -147,7 +160,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
             s[4] += wt * mu_u * mu_u + wh * mu_w * mu_w;
         }
     }
-    __shared__ double red[EDGE_BLOCK / WAVE][5];
+    __shared__ double red[EDGE_BLOCK][5];
+    __shared__ int is_last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -158,12 +172,43 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
     if (threadIdx.x < 5) {
         double t = 0;
         for (int q = 0; q < EDGE_BLOCK / WAVE; ++q) t += red[q][threadIdx.x];
-        a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
-        if (FUSED) sums[threadIdx.x] = t;      // one workgroup: its partial is the sum (what finalize_kernel would produce)
+        if (MODE == 2) __hip_atomic_store(&a.partials[(size_t)blockIdx.x * 5 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
+        if (MODE == 1) sums[threadIdx.x] = t;      // one workgroup: its partial is the sum (what finalize_kernel would produce)
     }
-    if (FUSED) {
+    if (MODE == 1) {
         __syncthreads();
         if (threadIdx.x == 0) control_body(cb, sums, cp, counters, trace);
+    }
+    if (MODE == 2) {
+        // hand-off of the partials to the last workgroup (MI355X_MICROARCH.md, inter-workgroup visibility): write-through (sc1)
+        // stores by the first wavefront, drained, then ONE agent-scope ticket add by a lane of that same wavefront; the
+        // workgroup whose add returns gridDim.x - 1 came last and reads every partial with sc1 loads.
+        if (threadIdx.x < WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = (t == gridDim.x - 1);
+        }
+        __syncthreads();
+        if (!is_last) return;
+        const int nblocks = gridDim.x;
+        double acc[5] = {0, 0, 0, 0, 0};
+        for (int b = threadIdx.x; b < nblocks; b += EDGE_BLOCK)
+            for (int k = 0; k < 5; ++k) acc[k] += __hip_atomic_load(&a.partials[(size_t)b * 5 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();       // red[][] above has been consumed by every thread
+        for (int k = 0; k < 5; ++k) red[threadIdx.x][k] = acc[k];
+        __syncthreads();
+        for (int off = EDGE_BLOCK / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off)
+                for (int k = 0; k < 5; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+            __syncthreads();
+        }
+        if (threadIdx.x < 5) sums[threadIdx.x] = red[0][threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            control_body(cb, sums, cp, counters, trace);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        }
     }
 }
 
@@ -184,27 +229,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *partials, i
         __syncthreads();
     }
     if (threadIdx.x < 5) sums[threadIdx.x] = red[0][threadIdx.x];
-}
-
-// the same reduction followed by the control step (gcsadmm_run: one launch instead of two)
-__global__ __launch_bounds__(256) void finalize_control_kernel(const double *partials, int nblocks, double *sums, gcsadmm_control_block *cb,
-                                                              ControlParams cp, int *counters, double *trace)
-{
-    if (cb->status != GCSADMM_RUNNING) return;
-    __shared__ double red[256][5];
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += 256)
-        for (int k = 0; k < 5; ++k) s[k] += partials[(size_t)b * 5 + k];
-    for (int k = 0; k < 5; ++k) red[threadIdx.x][k] = s[k];
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int k = 0; k < 5; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
-        __syncthreads();
-    }
-    if (threadIdx.x < 5) sums[threadIdx.x] = red[0][threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) control_body(cb, sums, cp, counters, trace);
 }
 
 // halo of a vertex partition: copies of the cut edges' coupled words, packed per neighbour as [c][columns of that peer]
@@ -284,6 +308,7 @@ struct gcsadmm_handle_s {
     gcsadmm_control_block *d_cb = nullptr;
     int *d_counters = nullptr;
     double *d_partials = nullptr, *d_sums = nullptr;
+    unsigned *d_ticket = nullptr;     // arrival counter of the single-launch edge step (edge_kernel MODE 2)
     std::vector<hipEvent_t> events;
     std::string err;
     // vertex partition across GPUs (gcsadmm_attach_comm): RCCL communicator, halo index lists and message buffers
@@ -431,12 +456,18 @@ template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcs
     a.E = h->E; a.NI = h->NI; a.c = h->c; a.edge_inc_tail = h->d_edge_inc_tail; a.edge_inc_head = h->d_edge_inc_head;
     a.inc_counted = h->d_inc_counted; a.edge_counted = h->d_edge_counted;
     a.copy = (const T *)st->copy; a.zedge = (T *)st->zedge; a.mu = (T *)st->mu; a.partials = h->d_partials;
-    if (with_control && h->edge_blocks == 1) {
-        hipLaunchKernelGGL((edge_kernel<T, true>), dim3(1), dim3(EDGE_BLOCK), 0, s, a, h->d_cb, sums, cp, h->d_counters, trace);
-    } else {
-        hipLaunchKernelGGL((edge_kernel<T, false>), dim3(h->edge_blocks), dim3(EDGE_BLOCK), 0, s, a, h->d_cb, sums, cp, h->d_counters, trace);
-        if (with_control) hipLaunchKernelGGL(finalize_control_kernel, dim3(1), dim3(256), 0, s, h->d_partials, h->edge_blocks, sums, h->d_cb, cp, h->d_counters, trace);
-        else hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, h->d_partials, h->edge_blocks, sums, h->d_cb);
+    // one kernel instantiation per (state type, mode, words per copy)
+    auto go = [&](auto mode, int blocks) {
+        constexpr int M = decltype(mode)::value;
+#define GCS_EDGE(CC) hipLaunchKernelGGL((edge_kernel<T, M, CC>), dim3(blocks), dim3(EDGE_BLOCK), 0, s, a, h->d_cb, sums, cp, h->d_counters, trace, h->d_ticket)
+        if (h->c == 5) GCS_EDGE(5); else if (h->c == 7) GCS_EDGE(7); else GCS_EDGE(13);
+#undef GCS_EDGE
+    };
+    if (with_control && h->edge_blocks == 1) go(std::integral_constant<int, 1>(), 1);
+    else if (with_control) go(std::integral_constant<int, 2>(), h->edge_blocks);
+    else {
+        go(std::integral_constant<int, 0>(), h->edge_blocks);
+        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, h->d_partials, h->edge_blocks, sums, h->d_cb);
     }
     HIPCHK(h, hipGetLastError());
     return GCSADMM_OK;
@@ -542,7 +573,7 @@ void gcsadmm_destroy(gcsadmm_handle h)
     DeviceGuard device_guard_(h->device);
     void *ptrs[] = {h->d_inc_ptr, h->d_deg_in, h->d_inc_edge, h->d_poly_ptr, h->d_edge_inc_tail, h->d_edge_inc_head,
                     h->d_wave_slot_ptr, h->d_wave_vtx, h->d_special_vtx, h->d_special_kind, h->d_wg_vtx, h->d_poly_A, h->d_poly_bc,
-                    h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums};
+                    h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums, h->d_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)h->d_send_cols, (void *)h->d_send_base, (void *)h->d_send_stride, (void *)h->d_recv_cols, (void *)h->d_recv_base,
@@ -763,6 +794,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_counters, (const int *)nullptr, 2);
     UP(d_partials, (const double *)nullptr, (size_t)h->edge_blocks * 5);
     UP(d_sums, (const double *)nullptr, 5);
+    UP(d_ticket, (const unsigned *)nullptr, 1);
 #undef UP
     if (h->lds_bytes > 48 * 1024) {
         e = h->dtype == GCSADMM_F64 ? set_lds_attr<2, double>(h->all_m4, h->lds_bytes) : set_lds_attr<2, float>(h->all_m4, h->lds_bytes);

@@ -126,7 +126,7 @@ template <int N> struct WSoc {   // cone block
     static constexpr int SS = 0, LS = Q, WB = 2 * Q, LT = 3 * Q, CV = LT + Q, SU = CV + N, DSSA = SU + N * N, DLSA = DSSA + Q,
                          DSS = DLSA + Q, DLS = DSS + Q, KS = DLS + Q, SIZE = KS + Q;
 };
-enum { SC_T = 0, SC_DT, SC_DTA, SC_ALPHA, SC_CONEFAIL, SC_C0, SC_ETA, SC_GT, SC_N = 8 };
+enum { SC_T = 0, SC_DT, SC_DTA, SC_ALPHA, SC_CONEFAIL, SC_C0, SC_ETA, SC_GT, SC_AMAXC, SC_C1C, SC_C2C, SC_N = 12 };
 template <int N> struct WL {
     using D = WD<N>;
     static constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1;
@@ -629,6 +629,29 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_SYNC();
         WG_STAMP(33);
     };
+    // the cone's part of a direction, by the cone thread as soon as (d zeta, dt) exist (inside solve_tail, beside the d nu
+    // tasks): slack / dual directions of the cone, its step bound and (affine direction) its share of the mu_aff sums
+    auto cone_step = [&](int dt_slot, bool wk) {
+        const double *u0 = UN(0);
+        const int oDS = wk ? SO::DSS : SO::DSSA, oDL = wk ? SO::DLS : SO::DLSA;
+        SOC[oDS] = SC[dt_slot];
+        for (int k = 0; k < N; ++k) SOC[oDS + 1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
+        {
+            double wb[Q], xs[Q], ys[Q];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) { wb[k] = SOC[SO::WB + k]; xs[k] = SOC[oDS + k]; }
+            soc_apply_W2<Q>(wb, SC[SC_ETA], xs, ys);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) SOC[oDL + k] = (wk ? SOC[SO::KS + k] : 0.0) - SOC[SO::LS + k] - ys[k];
+        }
+        SC[SC_AMAXC] = fmin(gcs_math::soc_max_step<Q>(SOC + SO::SS, SOC + oDS), gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + oDL));
+        double c1c = 0, c2c = 0;
+        for (int k = 0; k < Q; ++k) {
+            c1c += SOC[SO::SS + k] * SOC[oDL + k] + SOC[SO::LS + k] * SOC[oDS + k];
+            c2c += SOC[oDS + k] * SOC[oDL + k];
+        }
+        SC[SC_C1C] = c1c; SC[SC_C2C] = c2c;
+    };
     auto solve_tail = [&](int dt_slot, bool wk) {
         WG_FOR(q, NB1) {
             const double *Mi = sm + (NB1 <= 13 ? W::MINV : W::M) + q * NB1;
@@ -662,6 +685,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(36);
+        WG_CONE() cone_step(dt_slot, wk);
         WG_FOR(t, 2 * NW) {      // d nu_s = Bs^{-1} w_s
             const int s = t / NW, i = t - s * NW;
             const double *Bsi = sm + W::BSI + s * NW * NW;
@@ -1031,25 +1055,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             c1 += s5 * dl5 + l5 * dy + s6 * dl6 - l6 * dy; c2 += dy * dl5 - dy * dl6;
             un[W::KB] = dy * dl5; un[W::KB + 1] = -dy * dl6;
         }
+        // the cone's share (step bound, mu_aff sums) was computed by the cone thread inside the solve (cone_step)
         double amax_cone = 1e300;
-        WG_CONE() {
-            const double *u0 = UN(0);
-            SOC[SO::DSSA] = SC[SC_DTA];
-            for (int k = 0; k < N; ++k) SOC[SO::DSSA + 1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
-            {
-                double wb[Q], xs[Q], ys[Q];
-#pragma unroll
-                for (int k = 0; k < Q; ++k) { wb[k] = SOC[SO::WB + k]; xs[k] = SOC[SO::DSSA + k]; }
-                soc_apply_W2<Q>(wb, SC[SC_ETA], xs, ys);
-#pragma unroll
-                for (int k = 0; k < Q; ++k) SOC[SO::DLSA + k] = -SOC[SO::LS + k] - ys[k];
-            }
-            amax_cone = fmin(gcs_math::soc_max_step<Q>(SOC + SO::SS, SOC + SO::DSSA), gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + SO::DLSA));
-            for (int k = 0; k < Q; ++k) {
-                c1 += SOC[SO::SS + k] * SOC[SO::DLSA + k] + SOC[SO::LS + k] * SOC[SO::DSSA + k];
-                c2 += SOC[SO::DSSA + k] * SOC[SO::DLSA + k];
-            }
-        }
+        WG_CONE() { amax_cone = SC[SC_AMAXC]; c1 += SC[SC_C1C]; c2 += SC[SC_C2C]; }
         const Red3 rb = wg_reduce(Red3{fmin(rmax > 0.0 ? rcp1(rmax) : 1e300, amax_cone), c1, c2}, sm + W::RED, red_phase);
         WG_STAMP(14);
         double sigmu;
@@ -1075,7 +1083,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             un[W::KB] = (sigmu - un[W::KB]) * rcp1(yy);
             un[W::KB + 1] = (sigmu - un[W::KB + 1]) * rcp1(1.0 - yy);
         }
-        WG_CONE() {   // kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) )
+        WG_SYNC();
+        WG_STAMP(15);
+        WG_CONE() {   // (beside the G'kappa tasks: the last wavefront has none) kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) )
             double wb[Q], a1[Q], a2[Q], pr[Q], qv[Q], xs[Q], lt[Q], ss[Q];
             const double eta = SC[SC_ETA];
 #pragma unroll
@@ -1104,8 +1114,6 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             for (int i = 0; i < Q; ++i) SOC[SO::KS + i] = smd * (i == 0 ? ss[0] : -ss[i]) - a1[i];
             SC[SC_GT] = 1.0 - SOC[SO::KS];
         }
-        WG_SYNC();
-        WG_STAMP(15);
         // G' kappa per unit: own unknowns (GU) and the x part (GX); one loop per kind of task (uniform wavefronts)
         Place plg;
         WG_FOR_AT(t, U * 2 * N, plg.at(U * 2 * N)) {
@@ -1163,20 +1171,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             rmax = fmax(rmax, fmax(fmax(-dy * i5, -dl5 * rcp1(l5)), fmax(dy * i6, -dl6 * rcp1(l6))));
         }
         amax_cone = 1e300;
-        WG_CONE() {
-            const double *u0 = UN(0);
-            SOC[SO::DSS] = SC[SC_DT];
-            for (int k = 0; k < N; ++k) SOC[SO::DSS + 1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
-            {
-                double wb[Q], xs[Q], ys[Q];
-#pragma unroll
-                for (int k = 0; k < Q; ++k) { wb[k] = SOC[SO::WB + k]; xs[k] = SOC[SO::DSS + k]; }
-                soc_apply_W2<Q>(wb, SC[SC_ETA], xs, ys);
-#pragma unroll
-                for (int k = 0; k < Q; ++k) SOC[SO::DLS + k] = SOC[SO::KS + k] - SOC[SO::LS + k] - ys[k];
-            }
-            amax_cone = fmin(gcs_math::soc_max_step<Q>(SOC + SO::SS, SOC + SO::DSS), gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + SO::DLS));
-        }
+        WG_CONE() amax_cone = SC[SC_AMAXC];
         const Red3 rd = wg_reduce(Red3{fmin(rmax > 0.0 ? rcp1(rmax) : 1e300, amax_cone), 0.0, 0.0}, sm + W::RED, red_phase);
         WG_STAMP(19);
         WG_CONE() {      // step length with the cone guard (round-off must not push either cone point outside)
