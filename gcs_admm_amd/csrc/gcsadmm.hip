@@ -308,7 +308,9 @@ struct gcsadmm_handle_s {
     gcsadmm_control_block *d_cb = nullptr;
     int *d_counters = nullptr;
     double *d_partials = nullptr, *d_sums = nullptr;
-    unsigned *d_ticket = nullptr;     // arrival counter of the single-launch edge step (edge_kernel MODE 2)
+    unsigned *d_ticket = nullptr;
+    // prox configuration (gcsadmm_vertex_prox): every non-terminal vertex, LDS of the border-only problem, own counters
+    int *d_prox_vtx = nullptr, *d_prox_counters = nullptr, n_prox = 0, prox_lds_bytes = 0, src = -1, dst = -1;     // arrival counter of the single-launch edge step (edge_kernel MODE 2)
     std::vector<hipEvent_t> events;
     std::string err;
     // vertex partition across GPUs (gcsadmm_attach_comm): RCCL communicator, halo index lists and message buffers
@@ -573,7 +575,7 @@ void gcsadmm_destroy(gcsadmm_handle h)
     DeviceGuard device_guard_(h->device);
     void *ptrs[] = {h->d_inc_ptr, h->d_deg_in, h->d_inc_edge, h->d_poly_ptr, h->d_edge_inc_tail, h->d_edge_inc_head,
                     h->d_wave_slot_ptr, h->d_wave_vtx, h->d_special_vtx, h->d_special_kind, h->d_wg_vtx, h->d_poly_A, h->d_poly_bc,
-                    h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums, h->d_ticket};
+                    h->d_center, h->d_inc_counted, h->d_edge_counted, h->d_cb, h->d_counters, h->d_partials, h->d_sums, h->d_ticket, h->d_prox_vtx, h->d_prox_counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)h->d_send_cols, (void *)h->d_send_base, (void *)h->d_send_stride, (void *)h->d_recv_cols, (void *)h->d_recv_base,
@@ -795,6 +797,18 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_partials, (const double *)nullptr, (size_t)h->edge_blocks * 5);
     UP(d_sums, (const double *)nullptr, 5);
     UP(d_ticket, (const unsigned *)nullptr, 1);
+    {
+        std::vector<int> pv;
+        int mm_all = 1;
+        for (int v = 0; v < V; ++v) {
+            if (v != g->src && v != g->dst) pv.push_back(v);
+            mm_all = std::max(mm_all, g->poly_ptr[v + 1] - g->poly_ptr[v]);
+        }
+        h->n_prox = (int)pv.size(); h->src = g->src; h->dst = g->dst;
+        h->prox_lds_bytes = gcsadmm_wg_lds_bytes(n, 1, mm_all);
+        UP(d_prox_vtx, pv.data(), pv.size());
+        UP(d_prox_counters, (const int *)nullptr, 2);
+    }
 #undef UP
     if (h->lds_bytes > 48 * 1024) {
         e = h->dtype == GCSADMM_F64 ? set_lds_attr<2, double>(h->all_m4, h->lds_bytes) : set_lds_attr<2, float>(h->all_m4, h->lds_bytes);
@@ -952,6 +966,30 @@ gcsadmm_status gcsadmm_run_partitioned(gcsadmm_handle h, const gcsadmm_state *st
         if (h->comm) NCCLCHK(h, rccl().AllReduce(h->d_sums6, h->d_sums6, 6, ncclFloat64, ncclSum, (ncclComm_t)h->comm, s));
         hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, s, h->d_cb, h->d_sums6, cp, h->d_counters, trace_dev, true);
         HIPCHK(h, hipGetLastError());
+    }
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_vertex_prox(gcsadmm_handle h, const double *q_dev, const double *c_dev, double *xv_dev, double *zv_dev,
+                                   double *yv_dev, double ipm_tol, int32_t ipm_max_iter, int32_t *failures_host, void *stream)
+{
+    if (!h || !q_dev || !c_dev || !xv_dev || !zv_dev || !yv_dev || !(ipm_tol > 0) || ipm_max_iter < 1) { if (h) h->err = "bad prox argument"; return GCSADMM_ERR_BAD_ARG; }
+    if (h->prox_lds_bytes > 160 * 1024) { h->err = "facet count too large for LDS"; return GCSADMM_ERR_UNSUPPORTED; }
+    USE_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipMemsetAsync(h->d_prox_counters, 0, 2 * sizeof(int), s));
+    WgLaunchDesc d{};
+    d.n = h->n; d.dtype = GCSADMM_F64; d.n_vtx = h->n_prox; d.lds_bytes = h->prox_lds_bytes; d.vtx = h->d_prox_vtx;
+    d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
+    d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
+    d.xv = xv_dev; d.zv = zv_dev; d.yv = yv_dev; d.counters = h->d_prox_counters; d.ipm_tol = ipm_tol; d.ipm_max_iter = ipm_max_iter;
+    gcsadmm_wg_launch_prox(d, q_dev, c_dev, h->src, h->dst, s);
+    HIPCHK(h, hipGetLastError());
+    if (failures_host) {      // optional: synchronises the stream
+        int cnt[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(cnt, h->d_prox_counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        *failures_host = cnt[0];
     }
     return GCSADMM_OK;
 }

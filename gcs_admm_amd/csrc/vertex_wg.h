@@ -136,13 +136,15 @@ template <int N> struct WL {
                          PIVS = BXS + pad2(2 * NW * NX), BG = PIVS + pad2(2 * NW), XBG = BG + pad2(2 * NW), XBX = XBG + pad2(2 * NX),
                          XS = XBX + pad2(2 * NX * NX), RP = XS + pad2(NX * N), VV = RP + pad2(2 * NW), WW = VV + pad2(2 * NW), M = WW + pad2(2 * NW),
                          MINV = M + pad2(NB1 * NB1), PIVM = MINV + pad2(NB1 * NB1), RHS = PIVM + pad2(NB1), SOL = RHS + pad2(NB1),
-                         SOC = SOL + pad2(NB1), SC = SOC + pad2(WSoc<N>::SIZE), RED = SC + pad2(SC_N), FIXED = RED + 3 * 3 * WG_WAVES;
+                         SOC = SOL + pad2(NB1), PQ = SOC + pad2(WSoc<N>::SIZE), PC = PQ + pad2(NX + NW), SC = PC + pad2(NX + NW), RED = SC + pad2(SC_N), FIXED = RED + 3 * 3 * WG_WAVES;
     // per-unit block (offsets from the unit's base); the three facet-row arrays (4m each) follow at ROWS
     static constexpr int P = 0, DW = P + pad2(NW), TG = DW + pad2(NW), TF = TG + pad2(NW), LB = TF + pad2(N), KB = LB + 2, DLB = KB + 2,
                          PIV = DLB + 2, G0 = PIV + pad2(NW), GU = G0 + pad2(NW), GX = GU + pad2(NW), TE = GX + pad2(NX),
                          RV = TE + pad2(NW), K = RV + pad2(NW), X = K + pad2(NW * NW), B = X + pad2(NW * NX), ROWS = B + pad2(NW * NW);
-    static GCS_HD int unit_stride(int m) { return ROWS + 12 * m; }
-    static GCS_HD int total(int U, int m) { return FIXED + U * unit_stride(m) + pad2(m * N) + pad2(m); }
+    // ODD number of doubles: threads that read the same field of different units (most regions do) then hit different LDS
+    // banks; with the natural even stride (e.g. 216 doubles at n = 2, m = 7) units 4 apart collide: 4-way conflicts
+    static GCS_HD int unit_stride(int m) { return (ROWS + 12 * m) | 1; }
+    static GCS_HD int total(int U, int m) { return FIXED + pad2(U * unit_stride(m)) + pad2(m * N) + pad2(m); }
 };
 template <int N> GCS_HD int wg_lds_doubles(int U, int m) { return WL<N>::total(U, m); }
 inline int wg_lds_doubles_n(int n, int U, int m)
@@ -167,6 +169,10 @@ template <class T> struct WgArgs {
     int *counters;              // [0] inner failures, [1] inner iterations
     double eps_edge, ipm_tol;
     int ipm_max_iter;
+    // PROX configuration (the x-update of the reference's vertex-edge splits, admm_solver_v1.py:334-383):
+    // no edge blocks; a separable quadratic 1/2 sum_k q_k (u_k - c_k)^2 on the border unknowns u = (x_v, z_v, y_v) instead of
+    // the consensus penalty.  [V][4n+1] each, order x (2n), z (2n), y; nullptr = the ADMM vertex step of the v3 solver.
+    const double *prox_q = nullptr, *prox_c = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -363,32 +369,88 @@ template <int DIM> GCS_HD void chol_inverse_col(const double *Lm, const double *
     for (int i = 0; i < DIM; ++i) out[i * ldo + c] = x[i];
 }
 
-// Inverse of a larger SPD matrix from its factor in two parallel regions: (1) column c of L^{-1} by forward substitution
-// (one thread per column, the column in registers), written to `linv` (lower triangle, row-major ld = DIM); (2) every
-// entry of A^{-1} = L^{-T} L^{-1} as a dot product of two columns of L^{-1}, written as a full symmetric matrix over
-// the factor (`Lm`, dead by then).  Half the dependent chain of the column solves above, no register copy of DIM^2/2.
+// Inverse of a larger SPD matrix (three tiles, e.g. 25 = 8 + 8 + 9) from its tiled factor, every step a parallel region:
+//   L^{-1} = [X11 0 0; X21 X22 0; X31 X32 X33],  Xii = Lii^{-1},  X21 = -X22 (L21 X11),  X32 = -X33 (L32 X22),
+//   X31 = -X33 (L31 X11 + L32 X21);  then A^{-1} = L^{-T} L^{-1} entry by entry.
+// `Lm` holds the factor (strictly lower part, inverse pivots in piv) and receives A^{-1} (full, symmetric); `linv` is a
+// DIM x DIM scratch.  The column-at-a-time solves of chol_inverse_col cost a dependent chain of 2 DIM rows per column.
 template <int DIM> GCS_HD void wg_inverse_big(double *Lm, const double *piv, double *linv)
 {
+    constexpr int NT = (DIM + 8) / 9, B1 = DIM / NT, B2 = 2 * DIM / NT;
+    static_assert(NT == 3, "three-tile plan");
+    constexpr int S0 = B1, S1 = B2 - B1, S2 = DIM - B2;
+    // (1) inverses of the three diagonal tiles, one thread per (tile, column), the column in registers; the rest of linv := 0
     WG_FOR(c, DIM) {
-        double x[DIM];
+        const int t0 = c < B1 ? 0 : (c < B2 ? B1 : B2), ts = c < B1 ? S0 : (c < B2 ? S1 : S2), cl = c - t0;
+        double x[9];
 #pragma unroll
-        for (int i = 0; i < DIM; ++i) {
-            double s = (i == c) ? 1.0 : 0.0;
+        for (int i = 0; i < 9; ++i) {
+            double sx = (i == cl) ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < i; ++k) s -= Lm[i * DIM + k] * x[k];     // x[k] = 0 above the diagonal
-            x[i] = s * piv[i];
-            WG_FENCE();
+            for (int k = 0; k < i; ++k) sx -= (i < ts ? Lm[(t0 + i) * DIM + t0 + k] : 0.0) * x[k];
+            x[i] = i < ts ? sx * piv[t0 + i] : 0.0;
         }
+        for (int i = 0; i < DIM; ++i)
+            if (i < t0 || i >= t0 + ts) linv[i * DIM + c] = 0.0;
 #pragma unroll
-        for (int i = 0; i < DIM; ++i) linv[i * DIM + c] = x[i];     // zeros above the diagonal
+        for (int il = 0; il < 9; ++il)
+            if (il < ts) linv[(t0 + il) * DIM + c] = x[il];
     }
     WG_SYNC();
-    WG_FOR(t, DIM * DIM) {
-        const int i = t / DIM, j = t - i * DIM;
-        if (i < j) continue;
+    // (2) T21 = L21 X11, T32 = L32 X22, T31a = L31 X11 (into linv's off-diagonal blocks)
+    WG_FOR(t, S1 * S0 + S2 * S1 + S2 * S0) {
+        int i, j, k0, kn;
+        if (t < S1 * S0) { i = B1 + t / S0; j = t % S0; k0 = 0; kn = S0; }
+        else if (t < S1 * S0 + S2 * S1) { const int q = t - S1 * S0; i = B2 + q / S1; j = B1 + q % S1; k0 = B1; kn = S1; }
+        else { const int q = t - S1 * S0 - S2 * S1; i = B2 + q / S0; j = q % S0; k0 = 0; kn = S0; }
         double acc = 0;
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) acc += linv[k * DIM + i] * linv[k * DIM + j];   // rows k < i hold zeros
+        for (int k = 0; k < 9; ++k) acc += k < kn ? Lm[i * DIM + k0 + k] * linv[(k0 + k) * DIM + j] : 0.0;
+        linv[i * DIM + j] = acc;
+    }
+    WG_SYNC();
+    // (3) X21 = -X22 T21 (into Lm's 21 block: L21 is dead)
+    WG_FOR(t, S1 * S0) {
+        const int i = B1 + t / S0, j = t % S0;
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc -= k < S1 ? linv[i * DIM + B1 + k] * linv[(B1 + k) * DIM + j] : 0.0;
+        Lm[i * DIM + j] = acc;
+    }
+    WG_SYNC();
+    // (4) T31 = T31a + L32 X21
+    WG_FOR(t, S2 * S0) {
+        const int i = B2 + t / S0, j = t % S0;
+        double acc = linv[i * DIM + j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += k < S1 ? Lm[i * DIM + B1 + k] * Lm[(B1 + k) * DIM + j] : 0.0;
+        linv[i * DIM + j] = acc;
+    }
+    WG_SYNC();
+    // (5) X32 = -X33 T32, X31 = -X33 T31 (into Lm's 32 and 31 blocks)
+    WG_FOR(t, S2 * (S1 + S0)) {
+        const int i = B2 + t / (S1 + S0), jj = t % (S1 + S0), j = jj < S1 ? B1 + jj : jj - S1;
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc -= k < S2 ? linv[i * DIM + B2 + k] * linv[(B2 + k) * DIM + j] : 0.0;
+        Lm[i * DIM + j] = acc;
+    }
+    WG_SYNC();
+    // (6) gather L^{-1} in linv (its off-diagonal blocks sit in Lm)
+    WG_FOR(t, S1 * S0 + S2 * (S1 + S0)) {
+        int i, j;
+        if (t < S1 * S0) { i = B1 + t / S0; j = t % S0; }
+        else { const int q = t - S1 * S0; i = B2 + q / (S1 + S0); j = q % (S1 + S0); j = j < S1 ? B1 + j : j - S1; }
+        linv[i * DIM + j] = Lm[i * DIM + j];
+    }
+    WG_SYNC();
+    // (7) A^{-1}[i][j] = sum_k Linv[k][i] Linv[k][j] (rows k < max(i, j) of L^{-1} hold zeros)
+    WG_FOR(t, DIM * (DIM + 1) / 2) {
+        int i, j;
+        tri_decode(t, i, j);
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) acc += linv[k * DIM + i] * linv[k * DIM + j];
         Lm[i * DIM + j] = acc;
         Lm[j * DIM + i] = acc;
     }
@@ -454,14 +516,16 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     using SO = WSoc<N>;
     using W = WL<N>;
     constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1, Q = D::Q, NS = D::NS, TA = D::TA;
-    const int lo = a.inc_ptr[v], d = a.inc_ptr[v + 1] - lo, d_in = a.deg_in[v], d_out = d - d_in;
+    const bool prox = a.prox_q != nullptr;       // border-only problem with a separable quadratic (no blocks, no sides)
+    const int lo = a.inc_ptr[v], d = prox ? 0 : a.inc_ptr[v + 1] - lo, d_in = prox ? 0 : a.deg_in[v], d_out = d - d_in;
+    const bool sides = d > 0;
     const int p0 = a.poly_ptr[v], m = a.poly_ptr[v + 1] - p0;
     const int U = d + 1, R = 4 * m, RT = U * R, m2 = 2 * m;
     const int US = W::unit_stride(m);
     const float inv_R = 1.0f / (float)R;
     auto UN = [&](int u) -> double * { return sm + W::FIXED + u * US; };       // base of unit u
     const int oLAM = W::ROWS, oR1 = W::ROWS + R, oR2 = W::ROWS + 2 * R;   // facet-row arrays of a unit: duals, two work arrays
-    double *const PA = sm + W::FIXED + U * US;
+    double *const PA = sm + W::FIXED + pad2(U * US);
     const double *A = PA, *BC = PA + pad2(m * N), *CEN = sm + W::CEN;
     double *SOC = sm + W::SOC, *SC = sm + W::SC;
     int red_phase = 0;
@@ -498,6 +562,12 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     }
     WG_FOR(k, NX) sm[W::XV + k] = 0.0;
     WG_FOR(k, 2 * NW) sm[W::NU + k] = 0.0;
+    if (prox) {
+        WG_FOR(k, NX + NW) {
+            sm[W::PQ + k] = a.prox_q[(size_t)v * (NX + NW) + k];
+            sm[W::PC + k] = a.prox_c[(size_t)v * (NX + NW) + k];
+        }
+    }
     WG_ONE() {
         SC[SC_T] = 1.0;
         SOC[SO::LS] = 1.0;
@@ -596,6 +666,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             double r;
             if (q < NX) {
                 r = -REG_DELTA * sm[W::XV + q] - sm[W::XBG + q] - sm[W::XBG + NX + q];
+                if (prox) r -= sm[W::PQ + q] * (sm[W::XV + q] + CEN[q < N ? q : q - N] - sm[W::PC + q]);
                 if (wk) {
 #pragma unroll 4
                     for (int u = 0; u <= d; ++u) r -= UN(u)[W::GX + q];
@@ -631,26 +702,29 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     };
     // the cone's part of a direction, by the cone thread as soon as (d zeta, dt) exist (inside solve_tail, beside the d nu
     // tasks): slack / dual directions of the cone, its step bound and (affine direction) its share of the mu_aff sums
-    auto cone_step = [&](int dt_slot, bool wk) {
-        const double *u0 = UN(0);
+    auto cone_step = [&](int part, int dt_slot, bool wk) {
+        // three parts, one per region of solve_tail (d nu, r_e, d w_e: all short and independent of the cone)
         const int oDS = wk ? SO::DSS : SO::DSSA, oDL = wk ? SO::DLS : SO::DLSA;
-        SOC[oDS] = SC[dt_slot];
-        for (int k = 0; k < N; ++k) SOC[oDS + 1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
-        {
+        if (part == 0) {
+            const double *u0 = UN(0);
             double wb[Q], xs[Q], ys[Q];
+            xs[0] = SC[dt_slot];
 #pragma unroll
-            for (int k = 0; k < Q; ++k) { wb[k] = SOC[SO::WB + k]; xs[k] = SOC[oDS + k]; }
+            for (int k = 0; k < N; ++k) xs[1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) wb[k] = SOC[SO::WB + k];
             soc_apply_W2<Q>(wb, SC[SC_ETA], xs, ys);
+            double c1c = 0, c2c = 0;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) SOC[oDL + k] = (wk ? SOC[SO::KS + k] : 0.0) - SOC[SO::LS + k] - ys[k];
-        }
-        SC[SC_AMAXC] = fmin(gcs_math::soc_max_step<Q>(SOC + SO::SS, SOC + oDS), gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + oDL));
-        double c1c = 0, c2c = 0;
-        for (int k = 0; k < Q; ++k) {
-            c1c += SOC[SO::SS + k] * SOC[oDL + k] + SOC[SO::LS + k] * SOC[oDS + k];
-            c2c += SOC[oDS + k] * SOC[oDL + k];
-        }
-        SC[SC_C1C] = c1c; SC[SC_C2C] = c2c;
+            for (int k = 0; k < Q; ++k) {
+                const double dl = (wk ? SOC[SO::KS + k] : 0.0) - SOC[SO::LS + k] - ys[k];
+                SOC[oDS + k] = xs[k]; SOC[oDL + k] = dl;
+                c1c += SOC[SO::SS + k] * dl + SOC[SO::LS + k] * xs[k];
+                c2c += xs[k] * dl;
+            }
+            SC[SC_C1C] = c1c; SC[SC_C2C] = c2c;
+        } else if (part == 1) SC[SC_AMAXC] = gcs_math::soc_max_step<Q>(SOC + SO::SS, SOC + oDS);
+        else SC[SC_AMAXC] = fmin(SC[SC_AMAXC], gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + oDL));
     };
     auto solve_tail = [&](int dt_slot, bool wk) {
         WG_FOR(q, NB1) {
@@ -685,7 +759,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(36);
-        WG_CONE() cone_step(dt_slot, wk);
+        WG_CONE() cone_step(0, dt_slot, wk);
         WG_FOR(t, 2 * NW) {      // d nu_s = Bs^{-1} w_s
             const int s = t / NW, i = t - s * NW;
             const double *Bsi = sm + W::BSI + s * NW * NW;
@@ -696,6 +770,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(37);
+        WG_CONE() cone_step(1, dt_slot, wk);
         WG_FOR(t, d * NW) {      // r_e = -g_e + d nu_side - X_e dx
             const int u = 1 + t / NW, i = t - (u - 1) * NW;
             double *un = UN(u);
@@ -712,6 +787,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(38);
+        WG_CONE() cone_step(2, dt_slot, wk);
         WG_FOR(t, d * NW) {      // d w_e = B_e r_e
             const int u = 1 + t / NW, i = t - (u - 1) * NW;
             double *un = UN(u);
@@ -756,7 +832,19 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             double *un = UN(u);
             const double *p = un + W::P;
             double g;
-            if (u == 0) g = sm[W::NU + k] + sm[W::NU + NW + k] + REG_DELTA * p[k];
+            if (u == 0) {
+                g = sm[W::NU + k] + sm[W::NU + NW + k] + REG_DELTA * p[k];
+                if (prox) {     // z = p + y cen (the border unknowns are centred like the blocks'): q_z (z - c_z), chain rule for y
+                    const double *qz = sm + W::PQ + NX, *cz = sm + W::PC + NX;
+                    const double yy = p[2 * N];
+                    if (k < 2 * N) g += qz[k] * (p[k] + yy * CEN[k < N ? k : k - N] - cz[k]);
+                    else {
+                        g += qz[2 * N] * (yy - cz[2 * N]);
+#pragma unroll
+                        for (int c = 0; c < 2 * N; ++c) g += CEN[c < N ? c : c - N] * qz[c] * (p[c] + yy * CEN[c < N ? c : c - N] - cz[c]);
+                    }
+                }
+            }
             else {
                 const bool out = side_of(u);
                 const double *tg_ = un + W::TG, *nu = sm + W::NU + (out ? NW : 0);
@@ -836,7 +924,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const double *Da = un + oR1, *Db = Da + m2;
             const bool blk = u > 0, out = blk && side_of(u);
             int k, l;
-            tri_decode(pq, k, l);
+            if constexpr (N == 2) { k = pq > 0; l = pq > 1; }      // packed lower index of a 2 x 2 block: (0,0) (1,0) (1,1)
+            else tri_decode(pq, k, l);
             double sk = 0, sx = 0;
 #pragma unroll 4
             for (int j = 0; j < m; ++j) {
@@ -844,7 +933,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 sk += (Da[i * m + j] + Db[i * m + j]) * aa;
                 sx += Db[i * m + j] * aa;
             }
-            if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; }
+            if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; if (prox) sk += sm[W::PQ + NX + i * N + k]; }
             K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
             X[(i * N + k) * NX + i * N + l] = -sx; X[(i * N + l) * NX + i * N + k] = -sx;
             const int o = (1 - i) * N;      // the two halves are not coupled directly
@@ -864,6 +953,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 sx += Db[i * m + j] * ba;
             }
             if (blk && (i == 0 || out)) sk += rho * CEN[k];
+            if (prox) sk += sm[W::PQ + NX + i * N + k] * CEN[k];
             un[W::K + (i * N + k) * NW + 2 * N] = sk; un[W::K + 2 * N * NW + i * N + k] = sk;
             un[W::X + 2 * N * NX + i * N + k] = sx;
         }
@@ -881,6 +971,11 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll
                 for (int k = 0; k < N; ++k) cc += CEN[k] * CEN[k];
                 sk += rho * (1.0 + (out ? 2.0 : 1.0) * cc);
+            }
+            if (prox) {
+                sk += sm[W::PQ + NX + 2 * N];
+#pragma unroll
+                for (int k = 0; k < 2 * N; ++k) sk += sm[W::PQ + NX + k] * CEN[k < N ? k : k - N] * CEN[k < N ? k : k - N];
             }
             un[W::K + 2 * N * NW + 2 * N] = sk;
         }
@@ -957,21 +1052,28 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_SYNC();
         WG_STAMP(6);
         // ================= sides: factor, invert, Y_s = Bs^{-1} BXs (over the dead factor) =================
-        wg_chol<NW>(sm + W::BS, sm + W::PIVS, 2, NW * NW, NW);
-        WG_STAMP(7);
-        WG_FOR(t, 2 * NW) {
-            const int s = t / NW, c = t - s * NW;
-            chol_inverse_col<NW>(sm + W::BS + s * NW * NW, sm + W::PIVS + s * NW, c, sm + W::BSI + s * NW * NW, NW);
-        }
-        WG_SYNC();
         Place ply;
-        WG_FOR_AT(t, 2 * NW * NX, ply.at(2 * NW * NX)) {
-            const int s = t / (NW * NX), ic = t - s * NW * NX, i = ic / NX, c = ic - i * NX;
-            const double *Bsi = sm + W::BSI + s * NW * NW, *BXs = sm + W::BXS + s * NW * NX;
-            double acc2 = 0;
+        if (sides) {
+            wg_chol<NW>(sm + W::BS, sm + W::PIVS, 2, NW * NW, NW);
+            WG_STAMP(7);
+            WG_FOR(t, 2 * NW) {
+                const int s = t / NW, c = t - s * NW;
+                chol_inverse_col<NW>(sm + W::BS + s * NW * NW, sm + W::PIVS + s * NW, c, sm + W::BSI + s * NW * NW, NW);
+            }
+            WG_SYNC();
+            WG_FOR_AT(t, 2 * NW * NX, ply.at(2 * NW * NX)) {
+                const int s = t / (NW * NX), ic = t - s * NW * NX, i = ic / NX, c = ic - i * NX;
+                const double *Bsi = sm + W::BSI + s * NW * NW, *BXs = sm + W::BXS + s * NW * NX;
+                double acc2 = 0;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) acc2 += Bsi[i * NW + k] * BXs[k * NX + c];
-            sm[W::BS + s * NW * NW + ic] = acc2;     // Y_s
+                for (int k = 0; k < NW; ++k) acc2 += Bsi[i * NW + k] * BXs[k * NX + c];
+                sm[W::BS + s * NW * NW + ic] = acc2;     // Y_s
+            }
+        } else {
+            // no blocks (prox configuration): the side matrices and everything derived from them are zero -- Bs and BXs
+            // already are (empty sums), the formulas below then need Bs^{-1} := 0 and Y_s := 0 (= the Bs buffer as it stands)
+            WG_FOR(t, 2 * NW * NW) sm[W::BSI + t] = 0.0;
+            WG_SYNC();
         }
         v_tasks(ply);                    // affine solve, head 3/4
         WG_SYNC();
@@ -986,7 +1088,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             WG_FOR_AT(t, NX * (NX + 1) / 2, plm.at(NX * (NX + 1) / 2)) {        // x-x
                 int r, c;
                 tri_decode(t, r, c);
-                double val = (r == c ? REG_DELTA : 0.0) - sm[W::XBX + r * NX + c] - sm[W::XBX + NX * NX + r * NX + c];
+                double val = (r == c ? REG_DELTA + (prox ? sm[W::PQ + r] : 0.0) : 0.0) - sm[W::XBX + r * NX + c] - sm[W::XBX + NX * NX + r * NX + c];
                 if (r / N == c / N) val -= sm[W::XS + r * N + (c - (c / N) * N)];
 #pragma unroll
                 for (int k = 0; k < NW; ++k)

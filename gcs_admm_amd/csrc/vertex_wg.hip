@@ -59,6 +59,56 @@ template <int N, class T> void launch(const WgLaunchDesc &d, hipStream_t s)
     hipLaunchKernelGGL((vertex_wg_kernel<N, T>), dim3(grid), dim3(WG_THREADS), lds, s, a, sp, d.cb);
 }
 
+// PROX configuration (admm_solver_v1.py:334-383): one workgroup per vertex, no edge blocks; the two trailing
+// threads handle the terminals, which are points: x = (pt, pt), z = y (pt, pt), y = the minimiser of the remaining 1-D quadratic
+// clamped to [0, 1] (the cone term vanishes: z_1 = z_2).
+template <int N>
+__global__ __launch_bounds__(WG_THREADS, 2) void vertex_prox_kernel(gcs_wg::WgArgs<double> a, int src, int dst)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NX = 2 * N, NU = 4 * N + 1;
+    if ((int)blockIdx.x >= a.n_vtx) {
+        const int t = (int)threadIdx.x;
+        const int v = t == 0 ? src : (t == 1 ? dst : -1);
+        if (v < 0) return;
+        const double *q = a.prox_q + (size_t)v * NU, *c = a.prox_c + (size_t)v * NU;
+        double num = q[2 * NX] * c[2 * NX], den = q[2 * NX];
+        for (int k = 0; k < NX; ++k) {
+            const double pt = a.center[(size_t)v * N + (k < N ? k : k - N)];
+            num += q[NX + k] * pt * c[NX + k];
+            den += q[NX + k] * pt * pt;
+        }
+        double y = den > 0.0 ? num / den : 0.5;
+        y = y < 0.0 ? 0.0 : (y > 1.0 ? 1.0 : y);
+        for (int k = 0; k < NX; ++k) {
+            const double pt = a.center[(size_t)v * N + (k < N ? k : k - N)];
+            a.xv[(size_t)v * NX + k] = pt;
+            a.zv[(size_t)v * NX + k] = y * pt;
+        }
+        a.yv[v] = y;
+        return;
+    }
+    int status = 0, iters = 0;
+    gcs_wg::wg_solve_vertex<N, double>(a, a.vtx[blockIdx.x], 1.0, 1.0, smem, status, iters);
+    if (threadIdx.x == 0 && a.counters) {
+        if (status != 0) atomicAdd(&a.counters[0], 1);
+        atomicAdd(&a.counters[1], iters);
+    }
+}
+
+template <int N> void launch_prox(const WgLaunchDesc &d, const double *q, const double *c, int src, int dst, hipStream_t s)
+{
+    gcs_wg::WgArgs<double> a{};
+    a.n_vtx = d.n_vtx; a.vtx = d.vtx;
+    a.inc_ptr = d.inc_ptr; a.deg_in = d.deg_in; a.inc_edge = d.inc_edge; a.poly_ptr = d.poly_ptr;
+    a.poly_A = d.poly_A; a.poly_bc = d.poly_bc; a.center = d.center;
+    a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
+    a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter; a.prox_q = q; a.prox_c = c;
+    if (d.lds_bytes > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)vertex_prox_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_bytes);
+    hipLaunchKernelGGL((vertex_prox_kernel<N>), dim3(d.n_vtx + 1), dim3(WG_THREADS), d.lds_bytes, s, a, src, dst);
+}
+
 template <int N, class T> hipError_t set_lds(int lds_bytes)
 {
     return hipFuncSetAttribute((const void *)vertex_wg_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -82,6 +132,13 @@ void gcsadmm_wg_launch(const WgLaunchDesc &d, hipStream_t s)
     if (d.n == 2) { if (f64) launch<2, double>(d, s); else launch<2, float>(d, s); }
     else if (d.n == 3) { if (f64) launch<3, double>(d, s); else launch<3, float>(d, s); }
     else { if (f64) launch<6, double>(d, s); else launch<6, float>(d, s); }
+}
+
+void gcsadmm_wg_launch_prox(const WgLaunchDesc &d, const double *q, const double *c, int src, int dst, hipStream_t s)
+{
+    if (d.n == 2) launch_prox<2>(d, q, c, src, dst, s);
+    else if (d.n == 3) launch_prox<3>(d, q, c, src, dst, s);
+    else launch_prox<6>(d, q, c, src, dst, s);
 }
 
 #ifdef GCS_WG_TIMING

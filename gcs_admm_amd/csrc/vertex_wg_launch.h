@@ -30,3 +30,7 @@ int gcsadmm_wg_lds_bytes(int n, int units, int facets);
 // raise the dynamic-LDS limit of the instantiation (needed above 48 KB)
 hipError_t gcsadmm_wg_set_lds(int n, int dtype, int lds_bytes);
 void gcsadmm_wg_launch(const gcsadmm_k::WgLaunchDesc &d, hipStream_t s);
+
+// PROX configuration of the workgroup program (gcsadmm_vertex_prox): every vertex of `vtx` solves the border-only problem with
+// the separable quadratic (q, c) [V][4n+1]; the two terminals (points) are closed form.  zedge / mu / copy of `d` are unused.
+void gcsadmm_wg_launch_prox(const gcsadmm_k::WgLaunchDesc &d, const double *q, const double *c, int src, int dst, hipStream_t s);

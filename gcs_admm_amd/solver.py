@@ -25,7 +25,7 @@ STATUS_NAME = {RUNNING: "running", CONVERGED: "converged", MAX_IT: "max_it", DIV
 
 EXPORTS = ["gcsadmm_create", "gcsadmm_destroy", "gcsadmm_last_error", "gcsadmm_reset", "gcsadmm_vertex_step",
            "gcsadmm_edge_step", "gcsadmm_control", "gcsadmm_run", "gcsadmm_run_timed", "gcsadmm_read_control",
-           "gcsadmm_cost", "gcsadmm_query",
+           "gcsadmm_cost", "gcsadmm_query", "gcsadmm_vertex_prox",
            # vertex partitions across GPUs (RCCL)
            "gcsadmm_comm_unique_id", "gcsadmm_attach_comm", "gcsadmm_run_partitioned", "gcsadmm_halo_pack", "gcsadmm_halo_unpack",
            "gcsadmm_halo_exchange", "gcsadmm_halo_buffers",
@@ -229,6 +229,22 @@ class DeviceSolver:
                                                self._stream(), C.byref(vm), C.byref(vl), C.byref(em), C.byref(el)),
                     "gcsadmm_run_timed")
         return dict(vertex_ms=vm.value, vertex_launches=vl.value, edge_ms=em.value, edge_launches=el.value)
+
+    def vertex_prox(self, q, c, ipm_tol: float = 1e-10, ipm_max_iter: int = 60):
+        """The x-update of the reference's vertex-edge splits (admm_solver_v1.py:334-383) for every vertex: q, c are
+        [V, 4n+1] (weights and centres of the separable quadratic on (x_v, z_v, y_v)).  Returns (xv, zv, yv, failures)."""
+        torch = self.torch
+        V, n = self.g.num_vertices, self.g.n
+        qd = torch.as_tensor(np.ascontiguousarray(q, dtype=np.float64), device=self.device)
+        cd = torch.as_tensor(np.ascontiguousarray(c, dtype=np.float64), device=self.device)
+        assert qd.shape == (V, 4 * n + 1) and cd.shape == qd.shape
+        xv = torch.zeros(V, 2 * n, dtype=torch.float64, device=self.device); zv = torch.zeros_like(xv)
+        yv = torch.zeros(V, dtype=torch.float64, device=self.device)
+        fails = C.c_int32(0)
+        self._check(self.lib.gcsadmm_vertex_prox(self.h, C.c_void_p(qd.data_ptr()), C.c_void_p(cd.data_ptr()), C.c_void_p(xv.data_ptr()),
+                                                 C.c_void_p(zv.data_ptr()), C.c_void_p(yv.data_ptr()), C.c_double(ipm_tol),
+                                                 C.c_int32(ipm_max_iter), C.byref(fails), self._stream()), "gcsadmm_vertex_prox")
+        return xv, zv, yv, fails.value
 
     # ---- vertex partition across GPUs -------------------------------------------------
     def unique_id(self) -> bytes:

@@ -171,6 +171,21 @@ gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int3
                                  float *edge_ms, int32_t *edge_launches);
 
 /* ---------------------------------------------------------------------------------------------
+ * The x-update of the reference's OTHER splittings: admm_solver_v1.py:334-383 (shared by v2) solves,
+ * per vertex, the border-only problem -- no edge blocks -- whose consensus penalty (:350-367) is a separable quadratic in the
+ * vertex's own unknowns:
+ *     min |z_v[:n] - z_v[n:]| + 1/2 sum_k q_k (u_k - c_k)^2,  u = (x_v [2n], z_v [2n], y_v),
+ *     s.t. A z_i <= y_v b,  A (x_i - z_i) <= (1 - y_v) b  (:371-381),  0 <= y_v <= 1  (:346).
+ * Same interior-point method and kernel as the v3 vertex step (workgroup program, "prox" configuration).  q_dev, c_dev:
+ * [V][4n+1] f64 device arrays (weights >= 0, not all zero per vertex; centres); outputs [V][2n], [V][2n], [V] f64 device arrays.
+ * The two terminals are points (closed form).  failures_host (may be NULL; non-NULL synchronises the stream) receives the
+ * number of inner solves that did not converge (their outputs are left untouched).  The edge side of those splittings -- one
+ * monolithic conic program over all edges (v1) or a sequential sweep (v2) -- is out of scope.
+ */
+gcsadmm_status gcsadmm_vertex_prox(gcsadmm_handle h, const double *q_dev, const double *c_dev, double *xv_dev, double *zv_dev,
+                                   double *yv_dev, double ipm_tol, int32_t ipm_max_iter, int32_t *failures_host, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Vertex partitions across GPUs.  The reference's fan-out point is admm_solver_v3.py:490
  * (SolveInParallel over all vertices); here each rank holds one handle built from its part of the graph (ghost incidence
  * columns for the remote endpoint of every cut edge, ownership masks, global nx / nmu: see gcsadmm_graph_desc) and the ranks

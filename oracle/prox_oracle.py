@@ -1,0 +1,77 @@
+"""CPU restatement of the x-update of the reference's vertex-edge splits (admm_solver_v1.py:334-383) in the separable form
+the C ABI takes (gcsadmm_vertex_prox): per vertex
+
+    min  |z_1 - z_2|_2 + 1/2 sum_k q_k (u_k - c_k)^2      u = (x_v [2n], z_v [2n], y_v)
+    s.t. A z_i <= y_v b,   A (x_i - z_i) <= (1 - y_v) b   (i = 1, 2;  admm_solver_v1.py:371-381),   0 <= y_v <= 1   (:346)
+
+(the consensus penalty (rho/2)|A x + B z + mu|^2 of :350-367 is separable in (x_v, z_v, y_v) for every non-terminal vertex:
+each of its rows touches exactly one of these unknowns).  TEST INFRASTRUCTURE ONLY.  Solved with scipy's SLSQP on the epigraph
+form with a smoothed norm, as SURVEY.md Appendix B.1 describes for its cross-check; accuracy ~1e-6.
+
+PARITY UNPINNED: the reference stores no output of this step on its own (its v1 records are whole-loop traces that also
+need the monolithic MOSEK edge update, which is out of scope), so this restatement is checked only against the KKT conditions
+it is built from, and the device against it."""
+import numpy as np
+from scipy.optimize import minimize
+
+
+def solve_prox(A, b, q, c, n):
+    """returns (x [2n], z [2n], y, objective)"""
+    A = np.asarray(A, float); b = np.asarray(b, float); q = np.asarray(q, float); c = np.asarray(c, float)
+    m = A.shape[0]
+    nu = 4 * n + 1
+
+    def unpack(u):
+        return u[:2 * n], u[2 * n:4 * n], u[4 * n]
+
+    def obj(w):
+        u, t = w[:nu], w[nu]
+        return t + 0.5 * float(np.sum(q * (u - c) ** 2))
+
+    def grad(w):
+        g = np.zeros(nu + 1)
+        g[:nu] = q * (w[:nu] - c)
+        g[nu] = 1.0
+        return g
+
+    cons = []
+    G = []
+    h = []
+    for i in range(2):
+        for j in range(m):
+            # A_j z_i - y b_j <= 0
+            r = np.zeros(nu + 1); r[2 * n + i * n:2 * n + (i + 1) * n] = A[j]; r[4 * n] = -b[j]
+            G.append(r); h.append(0.0)
+            # A_j (x_i - z_i) + y b_j <= b_j
+            r = np.zeros(nu + 1); r[i * n:(i + 1) * n] = A[j]; r[2 * n + i * n:2 * n + (i + 1) * n] = -A[j]; r[4 * n] = b[j]
+            G.append(r); h.append(b[j])
+    G = np.array(G); h = np.array(h)
+    cons.append({"type": "ineq", "fun": lambda w: h - G @ w, "jac": lambda w: -G})
+
+    def soc(w):
+        z = w[2 * n:4 * n]
+        return w[nu] - np.sqrt(np.sum((z[:n] - z[n:]) ** 2) + 1e-18)
+
+    def soc_jac(w):
+        z = w[2 * n:4 * n]
+        dlt = z[:n] - z[n:]
+        nn = np.sqrt(np.sum(dlt ** 2) + 1e-18)
+        g = np.zeros(nu + 1); g[nu] = 1.0
+        g[2 * n:3 * n] = -dlt / nn; g[3 * n:4 * n] = dlt / nn
+        return g
+    cons.append({"type": "ineq", "fun": soc, "jac": soc_jac})
+    bounds = [(None, None)] * (4 * n) + [(0.0, 1.0), (0.0, None)]
+    # strictly feasible start: x = z/y = an interior point (least-squares centre of the facets), y = 1/2
+    x0 = np.linalg.lstsq(A, b - 0.5 * np.min(np.abs(b)), rcond=None)[0] if m else np.zeros(n)
+    from gcs_admm_amd.graph import chebyshev_center
+    x0 = chebyshev_center(A, b)
+    w0 = np.concatenate([x0, x0, 0.5 * x0, 0.5 * x0, [0.5, 1.0]])
+    res = minimize(obj, w0, jac=grad, constraints=cons, bounds=bounds, method="SLSQP", options={"ftol": 1e-15, "maxiter": 1000})
+    x, z, y = unpack(res.x[:nu])
+    val = float(np.linalg.norm(z[:n] - z[n:]) + 0.5 * np.sum(q * (res.x[:nu] - c) ** 2))
+    return x, z, float(y), val
+
+
+def objective(q, c, x, z, y, n):
+    u = np.concatenate([x, z, [y]])
+    return float(np.linalg.norm(z[:n] - z[n:]) + 0.5 * np.sum(np.asarray(q) * (u - np.asarray(c)) ** 2))

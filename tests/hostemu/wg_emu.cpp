@@ -70,3 +70,42 @@ extern "C" int EMU_FN(int n, int V, int E, int NI, const int *inc_ptr, const int
     else run_all<6>(a, rho, mu_scale, lds, status, iters);
     return 0;
 }
+
+#ifdef GCS_WG_REVERSE
+#define EMU_PROX wg_emu_vertex_prox_rev
+#else
+#define EMU_PROX wg_emu_vertex_prox
+#endif
+// the PROX configuration of the same program (x-update of the vertex-edge splits, admm_solver_v1.py:334-383):
+// every vertex except the two terminals; q, c are [V][4n+1] (order x, z, y)
+extern "C" int EMU_PROX(int n, int V, const int *poly_ptr, const double *poly_A, const double *poly_b, const double *center,
+                        int src, int dst, const double *q, const double *c, double ipm_tol, int ipm_max_iter,
+                        double *xv, double *zv, double *yv, int *counters, int *status, int *iters)
+{
+    if (n != 2 && n != 3 && n != 6) return 1;
+    std::vector<int> vtx, zero(V + 1, 0);
+    int lds = 0;
+    for (int v = 0; v < V; ++v) {
+        status[v] = 0; iters[v] = 0;
+        if (v == src || v == dst) continue;
+        vtx.push_back(v);
+        lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, 1, poly_ptr[v + 1] - poly_ptr[v]));
+    }
+    std::vector<double> bc(poly_ptr[V]);
+    for (int v = 0; v < V; ++v)
+        for (int j = poly_ptr[v]; j < poly_ptr[v + 1]; ++j) {
+            double s = poly_b[j];
+            for (int k = 0; k < n; ++k) s -= poly_A[(size_t)j * n + k] * center[(size_t)v * n + k];
+            bc[j] = s;
+        }
+    gcs_wg::WgArgs<double> a{};
+    a.n_vtx = (int)vtx.size(); a.vtx = vtx.data();
+    a.inc_ptr = zero.data(); a.deg_in = zero.data(); a.inc_edge = zero.data(); a.poly_ptr = poly_ptr;
+    a.poly_A = poly_A; a.poly_bc = bc.data(); a.center = center; a.E = 0; a.NI = 0;
+    a.zedge = nullptr; a.mu = nullptr; a.copy = nullptr; a.xv = xv; a.zv = zv; a.yv = yv; a.counters = counters;
+    a.eps_edge = 0.0; a.ipm_tol = ipm_tol; a.ipm_max_iter = ipm_max_iter; a.prox_q = q; a.prox_c = c;
+    if (n == 2) run_all<2>(a, 1.0, 1.0, lds, status, iters);
+    else if (n == 3) run_all<3>(a, 1.0, 1.0, lds, status, iters);
+    else run_all<6>(a, 1.0, 1.0, lds, status, iters);
+    return 0;
+}

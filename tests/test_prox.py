@@ -1,0 +1,95 @@
+"""the x-update of the reference's vertex-edge splits (admm_solver_v1.py:334-383) as the "prox"
+configuration of the workgroup vertex program (gcsadmm_vertex_prox).
+
+PARITY UNPINNED against reference outputs: the reference stores no result of this step on its own (its v1 / v2 records are
+whole-loop traces that also need the monolithic MOSEK edge update, out of scope).  What is checked: the program (host build
+on CPU, device on GPU) against an independent restatement of the same convex problem (oracle/prox_oracle.py, scipy SLSQP on the
+epigraph form, accuracy ~1e-6): equal objective to 1e-7 relative, variables to 2e-4, feasibility to 1e-9."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from gcs_admm_amd.cases import load_fixture
+from gcs_admm_amd.graph import lattice_boxes
+from test_hostemu_wg import libs  # noqa: F401  (fixture: the host builds of the program)
+
+from oracle.prox_oracle import objective, solve_prox
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def random_prox_data(g, seed):
+    """weights and centres a v1-style loop would produce: centres near the set (x), near y c (z), y in [-0.2, 1.2]"""
+    rng = np.random.default_rng(seed)
+    V, n = g.num_vertices, g.n
+    nu = 4 * n + 1
+    q = rng.uniform(0.5, 3.0, size=(V, nu))
+    q[:, n:2 * n] = 0.0                    # admm_solver_v1.py:152-157: only the first n components of x_v carry consensus rows
+    c = np.zeros((V, nu))
+    for v in range(V):
+        cen = g.interior[v]
+        y = rng.uniform(-0.2, 1.2)
+        c[v, :2 * n] = np.tile(cen, 2) + rng.normal(0, 0.7, 2 * n)
+        c[v, 2 * n:4 * n] = y * np.tile(cen, 2) + rng.normal(0, 0.7, 2 * n)
+        c[v, 4 * n] = y
+    return q, c
+
+
+def check_against_restatement(g, q, c, xv, zv, yv, verts):
+    n = g.n
+    for v in verts:
+        A = g.poly_A[g.poly_ptr[v]:g.poly_ptr[v + 1]]; b = g.poly_b[g.poly_ptr[v]:g.poly_ptr[v + 1]]
+        x, z, y, val = solve_prox(A, b, q[v], c[v], n)
+        mine = objective(q[v], c[v], xv[v], zv[v], yv[v], n)
+        feas = max(np.max(A @ zv[v][:n] - yv[v] * b), np.max(A @ zv[v][n:] - yv[v] * b),
+                   np.max(A @ (xv[v][:n] - zv[v][:n]) - (1 - yv[v]) * b), np.max(A @ (xv[v][n:] - zv[v][n:]) - (1 - yv[v]) * b))
+        assert feas <= 1e-9 and -1e-12 <= yv[v] <= 1 + 1e-12
+        assert mine <= val + 1e-7 * max(1.0, abs(val))           # at least as good as the restatement's optimum
+        # the penalised unknowns are unique; x[n:] of a weightless half is free wherever the set allows (compare z, y, x[:n])
+        assert np.abs(np.concatenate([x[:n] - xv[v][:n], z - zv[v], [y - yv[v]]])).max() <= 2e-4
+
+
+def emu_prox(lib, fn, g, q, c):
+    V, n = g.num_vertices, g.n
+    xv = np.zeros((V, 2 * n)); zv = np.zeros((V, 2 * n)); yv = np.zeros(V)
+    cnt = np.zeros(2, np.int32); st = np.zeros(V, np.int32); it = np.zeros(V, np.int32)
+    assert getattr(lib, fn)(n, V, _p(g.poly_ptr), _p(g.poly_A), _p(g.poly_b), _p(g.interior), g.src, g.dst, _p(q), _p(c),
+                            C.c_double(1e-10), 60, _p(xv), _p(zv), _p(yv), _p(cnt), _p(st), _p(it)) == 0
+    return xv, zv, yv, cnt
+
+
+@pytest.mark.parametrize("name", ["benchmark4", "lattice n=3"])
+def test_prox_program_host_build(libs, name):
+    fwd, rev = libs
+    g = load_fixture("benchmark4")[1] if name == "benchmark4" else lattice_boxes(3, 3, n=3, seed=2)
+    q, c = random_prox_data(g, 1)
+    xv, zv, yv, cnt = emu_prox(fwd, "wg_emu_vertex_prox", g, q, c)
+    xr, zr, yr, _ = emu_prox(rev, "wg_emu_vertex_prox_rev", g, q, c)
+    assert cnt[0] == 0
+    assert np.abs(zv - zr).max() <= 1e-8 and np.abs(yv - yr).max() <= 1e-8       # task-order independence
+    verts = [v for v in range(g.num_vertices) if v not in (g.src, g.dst)][:12]
+    check_against_restatement(g, q, c, xv, zv, yv, verts)
+
+
+@pytest.mark.gpu
+def test_prox_on_device(libs):
+    from gcs_admm_amd.solver import DeviceSolver
+    fwd, _ = libs
+    for g in (load_fixture("benchmark4")[1], lattice_boxes(6, 5, n=6, seed=1)):
+        q, c = random_prox_data(g, 3)
+        d = DeviceSolver(g, "f64", device=0)
+        xv, zv, yv, fails = d.vertex_prox(q, c)
+        assert fails == 0
+        xv, zv, yv = xv.cpu().numpy(), zv.cpu().numpy(), yv.cpu().numpy()
+        xe, ze, ye, _ = emu_prox(fwd, "wg_emu_vertex_prox", g, q, c)
+        inner = np.array([v for v in range(g.num_vertices) if v not in (g.src, g.dst)])
+        assert np.abs(zv[inner] - ze[inner]).max() <= 1e-7 and np.abs(yv[inner] - ye[inner]).max() <= 1e-7     # device == host build
+        check_against_restatement(g, q, c, xv, zv, yv, inner[:8])
+        # terminals: points
+        for t in (g.src, g.dst):
+            assert np.allclose(xv[t], np.tile(g.interior[t], 2)) and 0.0 <= yv[t] <= 1.0
+            assert np.allclose(zv[t], yv[t] * np.tile(g.interior[t], 2))
