@@ -293,7 +293,7 @@ struct gcsadmm_handle_s {
     int n = 0, V = 0, E = 0, NI = 0, NI_owned = 0, c = 0, MM = 0, dtype = 0, device = 0;
     int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
     int n_wg = 0, wg_lds_bytes = 0;   // vertices solved by the workgroup program (vertex_wg.hip), LDS per workgroup
-    bool all_m4 = false;      // every generic vertex has exactly 4 facets -> the register-dual program
+    int all_m4 = 0;           // 1: every wavefront-program vertex has exactly 4 facets -> the register-dual program; 2: and all are canonical boxes
     int align_rows = 0;       // group placement rule (group_base)
     int store_dl = 0;         // LDS holds the final dual directions of the facet rows (kernel template SDL)
     double nx = 0, nmu = 0;
@@ -671,7 +671,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx, wg_vtx;
     std::vector<char> on_wave(V, 0);
     int wg_lds = 0, MMw = 1;
-    bool all_m4 = (n == 2) && !g->wave_generic_rows;
+    bool all_m4 = (n == 2) && g->wave_generic_rows != 1, all_box = all_m4 && g->wave_generic_rows != 2;
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v];
         const int m = g->poly_ptr[v + 1] - g->poly_ptr[v];
@@ -686,6 +686,11 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
             on_wave[v] = 1;
             MMw = std::max(MMw, m);
             if (m != 4) all_m4 = false;
+            if (all_m4 && all_box) {   // facet normals exactly [+e0, +e1, -e0, -e1]
+                static const double canon[8] = {1, 0, 0, 1, -1, 0, 0, -1};
+                const double *A = g->poly_A + (size_t)g->poly_ptr[v] * 2;
+                for (int k = 0; k < 8; ++k) if (A[k] != canon[k]) all_box = false;
+            }
         }
     }
     if (wg_lds > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "a vertex sub-problem (degree x facets) does not fit the 160 KB of LDS of a CU");
@@ -753,7 +758,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     h->dtype = g->state_dtype; h->device = g->device;
     h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
     h->slots_cap = std::max(1, max_slots_used);
-    h->all_m4 = all_m4; h->align_rows = align_rows;
+    h->all_m4 = all_m4 ? (all_box ? 2 : 1) : 0; h->align_rows = align_rows;
     if (n_waves > 0) {
         store_dl = 1;
         if (lds_need(h->slots_cap) > 40 * 1024) store_dl = 0;

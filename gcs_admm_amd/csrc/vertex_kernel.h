@@ -130,7 +130,7 @@ template <class LaneT, int RMODE> struct GpuExec {
     }
 };
 
-// the two instantiations of the wavefront program (vertex_program.h)
+// the three instantiations of the wavefront program (vertex_program.h); VertexLaunchDesc::all_m4 = 0 generic, 1 m4, 2 box
 struct ProgGeneric {   // any facet count per polytope, facet-row duals in LDS
     template <int N> using LaneT = gcs::Lane<N>;
     template <class T> using Args = gcs::VertexArgs<T>;
@@ -151,6 +151,18 @@ struct ProgM4 {        // every polytope has exactly 4 facets: unrolled facet lo
     static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
     {
         gcs_m4::run_vertex_program<N, T, SDL>(ex, w, a, S, rho, ms);
+    }
+};
+
+struct ProgBox {       // as ProgM4, every polytope an axis-aligned box in canonical facet order: facet normals are compile-time constants
+    template <int N> using LaneT = gcs_box::Lane<N>;
+    template <class T> using Args = gcs_box::VertexArgs<T>;
+    using Shared = gcs_box::WaveShared;
+    static __device__ __forceinline__ void shared_init(Shared &S, double *smem, int n, int mm, int dl) { gcs_box::wave_shared_init(S, smem, n, mm, dl); }
+    template <int N, class T, int SDL, class EX>
+    static __device__ __forceinline__ void run(EX &ex, int w, const Args<T> &a, const Shared &S, double rho, double ms)
+    {
+        gcs_box::run_vertex_program<N, T, SDL>(ex, w, a, S, rho, ms);
     }
 };
 
@@ -221,7 +233,8 @@ template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &
 {
     if (d.n_waves + d.n_special > 0) {
         if constexpr (N == 2) {     // the m = 4 program exists for n = 2 only
-            if (d.all_m4) launch_vertex_prog<ProgM4, N, T>(d, s);
+            if (d.all_m4 == 2) launch_vertex_prog<ProgBox, N, T>(d, s);
+            else if (d.all_m4) launch_vertex_prog<ProgM4, N, T>(d, s);
             else launch_vertex_prog<ProgGeneric, N, T>(d, s);
         } else {
             launch_vertex_prog<ProgGeneric, N, T>(d, s);
@@ -229,7 +242,7 @@ template <int N, class T> static void launch_vertex_dim(const VertexLaunchDesc &
     }
 }
 
-template <int N, class T> static hipError_t set_lds_attr(bool all_m4, int lds_bytes)
+template <int N, class T> static hipError_t set_lds_attr(int all_m4, int lds_bytes)
 {
     hipError_t e = hipSuccess;
     auto set = [&](const void *fn) { if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); };
@@ -243,6 +256,12 @@ template <int N, class T> static hipError_t set_lds_attr(bool all_m4, int lds_by
             set((const void *)vertex_kernel<ProgM4, N, T, 0, 1>);
             set((const void *)vertex_kernel<ProgM4, N, T, 1, 0>);
             set((const void *)vertex_kernel<ProgM4, N, T, 1, 1>);
+        }
+        if (all_m4 == 2) {
+            set((const void *)vertex_kernel<ProgBox, N, T, 0, 0>);
+            set((const void *)vertex_kernel<ProgBox, N, T, 0, 1>);
+            set((const void *)vertex_kernel<ProgBox, N, T, 1, 0>);
+            set((const void *)vertex_kernel<ProgBox, N, T, 1, 1>);
         }
     }
     return e;

@@ -83,7 +83,8 @@ typedef struct gcsadmm_graph_desc {
     int32_t wave_slots;              /* wavefront program: vertices per wavefront (0 auto) */
     int32_t wave_align;              /* wavefront program: 0 auto, 1 row-aligned groups, 2 dense packing */
     int32_t wave_store_dl;           /* wavefront program: 0 auto, 1 keep the facet-row dual directions in LDS, 2 recompute */
-    int32_t wave_generic_rows;       /* wavefront program: 1 = any-facet-count variant even when every polytope has 4 facets */
+    int32_t wave_generic_rows;       /* wavefront program: 1 = any-facet-count variant even when every polytope has 4 facets;
+                                        2 = the 4-facet variant without the axis-aligned-box specialisation (tuning / tests) */
     int32_t reserved0;
 } gcsadmm_graph_desc;
 

@@ -311,10 +311,11 @@ def test_degenerate_graphs(torch_gpu, oracle_lib):
                                    dict(wave_align=2, wave_slots=7, wave_generic_rows=1),
                                    dict(wave_align=1, wave_slots=3, wave_generic_rows=1),
                                    dict(wave_align=1, wave_store_dl=2), dict(wave_align=2, wave_store_dl=2, wave_generic_rows=1),
+                                   dict(wave_align=2, wave_slots=7, wave_generic_rows=2), dict(wave_align=1, wave_store_dl=2, wave_generic_rows=2),
                                    dict(program="workgroup")])
 def test_packing_and_reduction_modes(torch_gpu, oracle_lib, knobs):
     """every schedule of the vertex step (wavefront program: dense packing + chained wave shifts, row-aligned packing + DPP
-    row shifts, generic and 4-facet variant, 3 or 7 vertices per wavefront, update pass from stored directions or
+    row shifts, generic / 4-facet / canonical-box variant (the default on this lattice), 3 or 7 vertices per wavefront, update pass from stored directions or
     recomputed rows; workgroup program) gives the oracle's vertex step.  The schedule is part of the graph descriptor
     (include/gcsadmm.h), not of the process environment."""
     torch = torch_gpu

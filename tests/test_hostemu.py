@@ -68,8 +68,9 @@ def test_emulated_wave_program_matches_oracle(emu, oracle_lib, name, steps):
 
 
 def test_fixed_facet_variant_equals_generic(emu, oracle_lib):
-    """vertex_program.h instantiates the program twice (any facet count / exactly 4 facets with the row
-    duals in registers); on a graph of boxes both must produce the same numbers."""
+    """vertex_program.h instantiates the program three times (any facet count / exactly 4 facets with the row duals in
+    registers / canonical axis-aligned boxes with compile-time facet normals); on a lattice of boxes all must produce the
+    same numbers."""
     from gcs_admm_amd.graph import lattice_boxes
     g = lattice_boxes(7, 6, seed=2)
     o = oracle_lib.Oracle(g, ipm_tol=1e-9)
@@ -77,12 +78,14 @@ def test_fixed_facet_variant_equals_generic(emu, oracle_lib):
         z0, m0 = o.zedge.copy(), o.mu.copy()
         a = emu_step(emu, g, z0, m0, 1.0, 1.0)
         b = emu_step(emu, g, z0, m0, 1.0, 1.0, fn="emu_vertex_step_m4")
+        c = emu_step(emu, g, z0, m0, 1.0, 1.0, fn="emu_vertex_step_box")
         gen = a[5] == 1
         mask = np.zeros(2 * g.num_edges, bool)
         for v in np.nonzero(gen)[0]:
             mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
         assert np.abs(a[0][:, mask] - b[0][:, mask]).max() <= 1e-12
         assert np.abs(a[3][gen] - b[3][gen]).max() <= 1e-12
+        assert np.abs(c[0][:, mask] - b[0][:, mask]).max() <= 1e-12 and np.abs(c[3][gen] - b[3][gen]).max() <= 1e-12
         o.vertex_step(1.0, 1.0); o.edge_step(1.0)
 
 

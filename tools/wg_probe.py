@@ -32,8 +32,8 @@ def parity(name, g, program, steps=6, dtype="f64"):
     out[f"parity_{name}_{program}"] = dict(worst=worst, inner_failures=cb.inner_failures, q=d.query())
     print(name, program, "worst", worst, d.query(), flush=True)
 
-def rate(name, g, program, dtype, steps=100, warm=10):
-    d = DeviceSolver(g, dtype, device=0, program=program)
+def rate(name, g, program, dtype, steps=100, warm=10, **kw):
+    d = DeviceSolver(g, dtype, device=0, program=program, **kw)
     d.reset(max_it=steps + warm + 1, eps_abs=0.0, eps_rel=0.0)
     d.enqueue(warm); torch.cuda.synchronize()
     t0 = time.perf_counter(); d.enqueue(steps); torch.cuda.synchronize()
@@ -62,6 +62,12 @@ if "rate" in which:
         g = lattice_boxes(nx, ny, seed=0)
         for prog in ("workgroup", "wavefront"):
             rate(f"lat{nx}x{ny}", g, prog, "f32", steps=60, warm=5)
+if "box" in which:      # box specialisation of the wavefront program against its 4-facet variant
+    for (nx, ny) in ((45, 45), (100, 100), (317, 316)):
+        g = lattice_boxes(nx, ny, seed=0)
+        for dt in ("f32", "f64"):
+            rate(f"lat{nx}x{ny}_m4", g, "wavefront", dt, steps=60, warm=5, wave_generic_rows=2)
+            rate(f"lat{nx}x{ny}_box", g, "wavefront", dt, steps=60, warm=5)
 if "small" in which:
     case, g4 = load_fixture("benchmark4")
     rate("benchmark4", g4, "workgroup", "f64", steps=300, warm=20)
