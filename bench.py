@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--workload", default="benchmark4", choices=["benchmark4", "s10k", "s100k", "s6d"])
     ap.add_argument("--program", default="auto", choices=["auto", "wavefront", "workgroup"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--partition-timeout", type=int, default=240, help="seconds the sharded S100k leg may take at N > 1 before the line is printed without it")
     ap.add_argument("--loop-only", action="store_true",
                     help="only the timed loop and the per-kernel timing (no convergence runs, no CPU baseline): the "
                          "command to put under rocprofv3, so that its per-kernel averages cover the same launches as roofline.avg_launch_ms")
@@ -222,6 +223,20 @@ def main():
     # ---- the sharded path: BASELINE config 4, strong scaling, everything behind the C ABI ----
     if (world > 1 or args.workload == "benchmark4") and not args.loop_only:
         block, ok = {}, 1.0
+        watchdog = None
+        if world > 1:
+            # the headline measurement above is complete; if a rank never reaches one of this leg's collectives the line is still
+            # printed (with the error named) instead of the job hanging until the launcher's limit
+            import threading
+
+            def leg_timed_out():
+                if rank == 0:
+                    out["partitioned_s100k"] = {"error": f"timed out after {args.partition_timeout} s (a rank did not reach a collective of this leg)"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(args.partition_timeout + (0 if rank == 0 else 20), leg_timed_out)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             from gcs_admm_amd.graph import lattice_boxes
             from gcs_admm_amd.partition import device_partition
@@ -257,6 +272,8 @@ def main():
                     sel = time_loop(sdev, psteps, pwarm, pparams)
                     block["single_gpu_iterations_per_sec"] = psteps / sel
                     block["speedup_vs_1gpu"] = sel / pel
+        if watchdog is not None:
+            watchdog.cancel()
         if rank == 0:
             out["partitioned_s100k"] = block
     if rank == 0:

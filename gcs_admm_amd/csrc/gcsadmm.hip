@@ -351,7 +351,11 @@ RcclApi &rccl()
             a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (a.lib) break;
         }
-        if (!a.lib) { a.err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return a; }
+        if (!a.lib) {
+            const char *why = dlerror();      // (a second call would return NULL: the message is consumed)
+            a.err = std::string("dlopen(librccl): ") + (why ? why : "not found");
+            return a;
+        }
 #define RCCL_SYM(f) a.f = (decltype(a.f))dlsym(a.lib, "nccl" #f)
         RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommDestroy); RCCL_SYM(GroupStart); RCCL_SYM(GroupEnd);
         RCCL_SYM(Send); RCCL_SYM(Recv); RCCL_SYM(AllReduce); RCCL_SYM(GetErrorString);

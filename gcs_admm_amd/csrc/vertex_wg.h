@@ -61,6 +61,8 @@ __device__ __forceinline__ int wg_tid()
 #define WG_ONE() if (gcs_wg::wg_tid() == 0)
 // the serial cone algebra runs on the LAST thread: wave 3 has the fewest row / entry tasks in every region
 #define WG_CONE() if (gcs_wg::wg_tid() == gcs_wg::WG_THREADS - 1)
+// work that one WAVEFRONT does with a matrix row per lane (wave_ldl below): no barrier inside, broadcasts by readlane
+#define WG_WAVE0() if (gcs_wg::wg_tid() < 64)
 #define WG_FENCE() asm volatile("" ::: "memory")
 #else
 #define WG_FENCE() do { } while (0)
@@ -74,6 +76,7 @@ __device__ __forceinline__ int wg_tid()
 #define WG_SYNC() do { } while (0)
 #define WG_ONE() if (true)
 #define WG_CONE() if (true)
+#define WG_WAVE0() if (true)
 #endif
 
 // diagnostic build (-DGCS_WG_TIMING, tools/wg_phase_timing.py): thread 0 of workgroup 0 accumulates the s_memtime ticks
@@ -457,6 +460,92 @@ template <int DIM> GCS_HD void wg_inverse_big(double *Lm, const double *piv, dou
     WG_SYNC();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The reduced border system inside ONE wavefront.  A = L D L' (L unit lower) of one SPD matrix of dimension DIM <= 64
+// with one matrix ROW per lane in registers: the pivot and the pivot column reach the other lanes by readlane, so the
+// DIM dependent column steps cost no barrier and no LDS round trip (the tile-blocked wg_chol pays three barriers per
+// tile: 2 600 cycles at 9 x 9, 13 600 at 25 x 25, and the explicit inverse that followed it as much again; measured,
+// profiles/r02).  The two solves of a Newton iteration are substitutions with the unit factor (wave_ldl_solve): the chain
+// per step is one readlane + one FMA, there is no inverse.  Called by one wavefront (WG_WAVE0), the others wait at the
+// region's barrier.
+//   in : Mq  lower triangle of A (row-major, ld = DIM);   out: strictly lower part of Mq = L, rd[k] = 1 / D_k
+// (the diagonal and the upper triangle of Mq are left undefined).  Pivot rule of oracle chol(): a pivot that has
+// cancelled below CHOL_SKIP of its ORIGINAL diagonal entry is clamped there.
+// Host build: the same column-by-column elimination written serially.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
+{
+    static_assert(DIM <= 64, "one row per lane");
+#if WG_DEVICE
+    const int lane = wg_tid(), row = lane < DIM ? lane : DIM - 1;      // spare lanes shadow the last row and store nothing
+    double a[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) a[j] = Mq[row * DIM + j];
+    const double od = Mq[row * DIM + row];
+    double myr = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        double dk = lane_bcast(a[k], k);
+        const double odk = lane_bcast(od, k);
+        if (!(dk > CHOL_SKIP * odk)) dk = odk > 0.0 ? CHOL_SKIP * odk : 1.0;
+        const double rk = rcp(dk), col = a[k], l = col * rk;
+        a[k] = l;
+        if (lane == k) myr = rk;
+#pragma unroll
+        for (int j = k + 1; j < DIM; ++j) a[j] -= l * lane_bcast(col, j);     // (entries right of the diagonal: unused values)
+    }
+    if (lane < DIM) {
+#pragma unroll
+        for (int j = 0; j < DIM - 1; ++j) Mq[lane * DIM + j] = a[j];
+        rd[lane] = myr;
+    }
+#else
+    double od[DIM], col[DIM];
+    for (int k = 0; k < DIM; ++k) od[k] = Mq[k * DIM + k];
+    for (int k = 0; k < DIM; ++k) {
+        double dk = Mq[k * DIM + k];
+        if (!(dk > CHOL_SKIP * od[k])) dk = od[k] > 0.0 ? CHOL_SKIP * od[k] : 1.0;
+        const double rk = rcp(dk);
+        rd[k] = rk;
+        for (int i = k + 1; i < DIM; ++i) col[i] = Mq[i * DIM + k];
+        for (int i = k + 1; i < DIM; ++i) {
+            const double l = col[i] * rk;
+            Mq[i * DIM + k] = l;
+            for (int j = k + 1; j <= i; ++j) Mq[i * DIM + j] -= l * col[j];
+        }
+    }
+#endif
+}
+
+// x = A^{-1} b with the factor of wave_ldl: forward substitution with L, scaling by 1 / D, backward substitution with L'
+// (lane i owns b_i, row i of L for the forward sweep and column i for the backward sweep)
+template <int DIM> GCS_HD void wave_ldl_solve(const double *Mq, const double *rd, const double *b, double *x)
+{
+#if WG_DEVICE
+    const int lane = wg_tid(), row = lane < DIM ? lane : DIM - 1;
+    double l[DIM], v = b[row];
+#pragma unroll
+    for (int k = 0; k < DIM - 1; ++k) l[k] = k < row ? Mq[row * DIM + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM - 1; ++k) v -= l[k] * lane_bcast(v, k);
+    v *= rd[row];
+#pragma unroll
+    for (int k = 1; k < DIM; ++k) l[k] = k > row ? Mq[k * DIM + row] : 0.0;
+#pragma unroll
+    for (int k = DIM - 1; k >= 1; --k) v -= l[k] * lane_bcast(v, k);
+    if (lane < DIM) x[lane] = v;
+#else
+    double v[DIM];
+    for (int i = 0; i < DIM; ++i) v[i] = b[i];
+    for (int k = 0; k < DIM - 1; ++k)
+        for (int i = k + 1; i < DIM; ++i) v[i] -= Mq[i * DIM + k] * v[k];
+    for (int i = 0; i < DIM; ++i) v[i] *= rd[i];
+    for (int k = DIM - 1; k >= 1; --k)
+        for (int i = 0; i < k; ++i) v[i] -= Mq[k * DIM + i] * v[k];
+    for (int i = 0; i < DIM; ++i) x[i] = v[i];
+#endif
+}
+
 // Nesterov-Todd scaling of the cone from (s, z): wb (unit hyperbolic vector), eta; false on a boundary point
 template <int Q> GCS_HD bool soc_scaling_wb(const double *s, const double *z, double *wb, double &eta)
 {
@@ -727,13 +816,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         else SC[SC_AMAXC] = fmin(SC[SC_AMAXC], gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + oDL));
     };
     auto solve_tail = [&](int dt_slot, bool wk) {
-        WG_FOR(q, NB1) {
-            const double *Mi = sm + (NB1 <= 13 ? W::MINV : W::M) + q * NB1;
-            double acc = 0;
-#pragma unroll
-            for (int p = 0; p < NB1; ++p) acc += Mi[p] * sm[W::RHS + p];
-            sm[W::SOL + q] = acc;
-        }
+        WG_WAVE0() wave_ldl_solve<NB1>(sm + W::M, sm + W::PIVM, sm + W::RHS, sm + W::SOL);
         WG_SYNC();
         WG_STAMP(34);
         // solution back in (x, z1, z2, y_v): dz1 = du + dz2
@@ -1123,12 +1206,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(10);
-        wg_chol<NB1>(sm + W::M, sm + W::PIVM, 1, NB1 * NB1, NB1);
+        WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM);      // L D L' inside one wavefront; no explicit inverse
+        WG_SYNC();
         WG_STAMP(11);
-        if constexpr (NB1 <= 13) {
-            WG_FOR(c, NB1) chol_inverse_col<NB1>(sm + W::M, sm + W::PIVM, c, sm + W::MINV, NB1);
-            WG_SYNC();
-        } else wg_inverse_big<NB1>(sm + W::M, sm + W::PIVM, sm + W::MINV);      // the inverse ends up in M
         WG_STAMP(12);
         // ================= affine direction (kappa = 0) =================
         solve_tail(SC_DTA, false);      // the head of the affine solve rode in the factorisation regions above

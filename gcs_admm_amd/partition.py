@@ -188,19 +188,32 @@ def device_partition(g: GcsGraph, rank: int, world: int, state_dtype: str = "f32
     Returns (LocalPartition, DeviceSolver)."""
     import torch
     from .solver import DeviceSolver
-    owner = strip_owner(g, world) if owner is None else owner
-    part = build_partition(g, owner, rank, world)
-    dev = DeviceSolver(part.graph, state_dtype, device=device, num_incidences=part.num_incidences, inc_counted=part.inc_counted,
-                       edge_counted=part.edge_counted, nx_global=part.nx_global, nmu_global=part.nmu_global, **kw)
-    uid = None
+    err, part, dev, uid = None, None, None, None
+    try:       # everything local first: a rank that fails here must not leave the others waiting in a collective
+        owner = strip_owner(g, world) if owner is None else owner
+        part = build_partition(g, owner, rank, world)
+        dev = DeviceSolver(part.graph, state_dtype, device=device, num_incidences=part.num_incidences, inc_counted=part.inc_counted,
+                           edge_counted=part.edge_counted, nx_global=part.nx_global, nmu_global=part.nmu_global, **kw)
+        if world > 1 and rank == 0:
+            uid = dev.unique_id()
+    except Exception as exc:
+        err = exc
     if world > 1:
         import torch.distributed as dist
         backend = dist.get_backend(group)
-        tdev = dev.device if backend == "nccl" else torch.device("cpu")
+        tdev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device)) if backend == "nccl" else torch.device("cpu")
+        flag = torch.tensor([0.0 if err is not None else 1.0], device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if err is None and float(flag.item()) == 0.0:
+            err = RuntimeError("another rank failed to set up its partition")
+        if err is not None:
+            raise err
         t = torch.zeros(128, dtype=torch.uint8, device=tdev)
         if rank == 0:
-            t.copy_(torch.frombuffer(bytearray(dev.unique_id()), dtype=torch.uint8))
+            t.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
         dist.broadcast(t, src=0, group=group)
         uid = bytes(t.cpu().numpy().tobytes())
+    elif err is not None:
+        raise err
     dev.attach_comm(rank, world, uid, part.send_idx, part.recv_idx)
     return part, dev

@@ -36,7 +36,7 @@ for wl in sys.argv[1:] or ["benchmark4", "lat6"]:
     main = [k for k in NAMES if k < 30]
     tot = sum(c1[k] for k in main if k not in (13, 18)) + c1[30:40].sum()
     iters = n1[21] / steps
-    print(f"{wl}: workgroup 0, {iters:.1f} Newton iterations per solve, {tot / steps:.0f} ticks per solve (s_memtime, 100 MHz)")
+    print(f"{wl}: workgroup 0, {iters:.1f} Newton iterations per solve, {tot / steps:.0f} s_memtime ticks per solve")
     for k in sorted(NAMES):
         if n1[k] > 0:
             print(f"  {k:2d} {NAMES[k]:32s} {100 * c1[k] / tot:6.2f} %   {c1[k] / n1[k]:9.1f} ticks/visit  x{n1[k] / steps:.1f}")
