@@ -33,20 +33,51 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Three objects compiled concurrently, then linked."""
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + UNIT_DEPS[LP] + UNIT_DEPS[WG]):
         return OUT
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    if verbose:
-        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    # the compiler's per-kernel resource remarks (registers, scratch, LDS) are kept next to each object: kernel_resources()
+    flags = ["-Rpass-analysis=kernel-resource-usage", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     objs, procs = [], []
     for src, name, extra in UNITS:
         obj = os.path.join(HERE, name)
         objs.append(obj)
-        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in UNIT_DEPS.get(src, DEPS)):
-            procs.append((name, subprocess.Popen([hipcc()] + flags + extra + ["-c", src, "-o", obj])))
-    for name, p in procs:
-        if p.wait() != 0:
+        if force or not os.path.exists(obj) or not os.path.exists(obj + ".resources.txt") or \
+                any(os.path.getmtime(obj) < os.path.getmtime(d) for d in UNIT_DEPS.get(src, DEPS)):
+            log = open(obj + ".resources.txt", "w")
+            procs.append((name, subprocess.Popen([hipcc()] + flags + extra + ["-c", src, "-o", obj], stderr=log), log))
+    for name, p, log in procs:
+        rc = p.wait()
+        log.close()
+        text = open(os.path.join(HERE, name) + ".resources.txt").read()
+        if verbose or rc != 0:
+            sys.stderr.write(text)
+        if rc != 0:
+            os.remove(os.path.join(HERE, name) + ".resources.txt")
             raise RuntimeError(f"hipcc failed on {name}")
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT])
     return OUT
+
+
+def kernel_resources() -> dict:
+    """{kernel name: {"vgprs": .., "agprs": .., "scratch": bytes per lane, "lds": static bytes}} of the last build, from the
+    compiler's resource remarks."""
+    import re
+    build()
+    out = {}
+    for _, name, _ in UNITS:
+        cur = None
+        for line in open(os.path.join(HERE, name) + ".resources.txt"):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = out.setdefault(m.group(1), {})
+                continue
+            if cur is None:
+                continue
+            for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                             ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+                m = re.search(pat, line)
+                if m:
+                    cur[key] = int(m.group(1))
+    return out
 
 
 def build_timing() -> str:

@@ -40,6 +40,7 @@ using gcs_math::sqrt_nr;
 #endif
 constexpr int WG_THREADS = GCS_WG_THREADS;        // threads per workgroup (a power of two, whole wavefronts)
 constexpr int WG_WAVES = WG_THREADS / 64;
+constexpr int WG_ITEM_WAVES = WG_WAVES > 1 ? WG_WAVES - 1 : 1;   // wavefronts that share the items of a wave-local pipeline
 constexpr double CHOL_SKIP = 1e-12;
 constexpr double REG_DELTA = 1e-7;   // Tikhonov term on every centred unknown except t (oracle/gcs_oracle.c REG_DELTA)
 
@@ -63,6 +64,22 @@ __device__ __forceinline__ int wg_tid()
 #define WG_CONE() if (gcs_wg::wg_tid() == gcs_wg::WG_THREADS - 1)
 // work that one WAVEFRONT does with a matrix row per lane (wave_ldl below): no barrier inside, broadcasts by readlane
 #define WG_WAVE0() if (gcs_wg::wg_tid() < 64)
+// WAVE-LOCAL PIPELINE.  Tasks (q, i): `count` items (units) are dealt round-robin to the first WG_ITEM_WAVES wavefronts (item q
+// belongs to wavefront q % WG_ITEM_WAVES; the last wavefront is left to the serial cone thread), i runs over the PER sub-tasks of
+// an item, shared by the lanes of the owning wavefront.  Successive WG_ITEM_FOR loops over the SAME items exchange data through
+// LDS with WG_WAVE_SYNC() only (a wavefront's LDS operations complete in order).  Measured (profiles/r02/README.md): this pays for
+// chains of SHORT steps (d nu -> r_e -> d w_e of a solve: 2 060 -> 1 800 cycles); for steps with real work per task (block
+// factor -> inverse -> products: 3 260 against 2 400 cycles; G'kappa -> t_e: 4 440 against 2 200; the head of the corrector
+// solve on one wavefront) the work of four wavefronts lands on one and the pipeline is SLOWER than barrier-separated regions
+// spread over all threads -- those stay regions.
+#define WG_ITEM_FOR(q, i, count, PER)                                                                                          \
+    for (int t_ = gcs_wg::wg_tid(), w_ = t_ >> 6, l_ = t_ & 63,                                                                \
+             n_ = w_ < gcs_wg::WG_ITEM_WAVES ? (((count) - w_ + gcs_wg::WG_ITEM_WAVES - 1) / gcs_wg::WG_ITEM_WAVES) * (PER) : 0;  \
+         l_ < n_; l_ += 64)                                                                                                    \
+        if (const int qq_ = l_ / (PER), i = l_ - qq_ * (PER), q = w_ + gcs_wg::WG_ITEM_WAVES * qq_; true)
+// a small step EVERY item wavefront repeats for itself (same values to the same words) instead of waiting at a barrier for one
+#define WG_REPL_FOR(i, cnt) for (int i = (gcs_wg::wg_tid() >> 6) < gcs_wg::WG_ITEM_WAVES ? (gcs_wg::wg_tid() & 63) : (cnt), i##_end = (cnt); i < i##_end; i += 64)
+#define WG_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define WG_FENCE() asm volatile("" ::: "memory")
 #else
 #define WG_FENCE() do { } while (0)
@@ -77,6 +94,9 @@ __device__ __forceinline__ int wg_tid()
 #define WG_ONE() if (true)
 #define WG_CONE() if (true)
 #define WG_WAVE0() if (true)
+#define WG_ITEM_FOR(q, i, count, PER) WG_FOR(t_, (count) * (PER)) if (const int q = t_ / (PER), i = t_ - q * (PER); true)
+#define WG_REPL_FOR(i, cnt) WG_FOR(i, cnt)
+#define WG_WAVE_SYNC() do { } while (0)
 #endif
 
 // diagnostic build (-DGCS_WG_TIMING, tools/wg_phase_timing.py): thread 0 of workgroup 0 accumulates the s_memtime ticks
@@ -88,10 +108,14 @@ __device__ unsigned long long g_wg_counts[64];
 #if defined(GCS_WG_TIMING) && WG_DEVICE
 __device__ __forceinline__ void wg_stamp(int id, unsigned long long &last)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // wavefront 0 of workgroup 0, as a wave-UNIFORM branch: every lane adds the same difference to the same word (one wavefront,
+    // one instruction: no race, no atomics).  A divergent `threadIdx.x == 0` here made the n = 6 instantiation spill beside the
+    // branch, and this compiler stored that spill under the branch's partial EXEC mask (all n = 6 solves failed in this build).
+    if (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        atomicAdd(&g_wg_cycles[id], t - last);
-        atomicAdd(&g_wg_counts[id], 1ull);
+        volatile unsigned long long *cyc = g_wg_cycles, *cnt = g_wg_counts;
+        cyc[id] = cyc[id] + (t - last);
+        cnt[id] = cnt[id] + 1ull;
         last = __builtin_amdgcn_s_memtime();
     }
 }
@@ -815,6 +839,10 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         } else if (part == 1) SC[SC_AMAXC] = gcs_math::soc_max_step<Q>(SOC + SO::SS, SOC + oDS);
         else SC[SC_AMAXC] = fmin(SC[SC_AMAXC], gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + oDL));
     };
+    // The tail of a solve.  (1) one wavefront: substitutions with the border factor; (2) w_s, dx, d zeta, dt spread over the
+    // threads; (3) a wave-local pipeline: every item wavefront repeats the 2 NW values of d nu_s for itself, then runs
+    // r_e -> d w_e for ITS units, while the cone thread (last wavefront) does the cone's three parts.  (Merging (1) and (2) into
+    // the one wavefront was measured slower: 2 250 against 1 830 cycles.)
     auto solve_tail = [&](int dt_slot, bool wk) {
         WG_WAVE0() wave_ldl_solve<NB1>(sm + W::M, sm + W::PIVM, sm + W::RHS, sm + W::SOL);
         WG_SYNC();
@@ -842,8 +870,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(36);
-        WG_CONE() cone_step(0, dt_slot, wk);
-        WG_FOR(t, 2 * NW) {      // d nu_s = Bs^{-1} w_s
+        WG_CONE() { cone_step(0, dt_slot, wk); cone_step(1, dt_slot, wk); cone_step(2, dt_slot, wk); }
+        WG_REPL_FOR(t, 2 * NW) {      // d nu_s = Bs^{-1} w_s
             const int s = t / NW, i = t - s * NW;
             const double *Bsi = sm + W::BSI + s * NW * NW;
             double acc = 0;
@@ -851,11 +879,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             for (int k = 0; k < NW; ++k) acc += Bsi[i * NW + k] * sm[W::WW + s * NW + k];
             sm[W::DNU + t] = acc;
         }
-        WG_SYNC();
-        WG_STAMP(37);
-        WG_CONE() cone_step(1, dt_slot, wk);
-        WG_FOR(t, d * NW) {      // r_e = -g_e + d nu_side - X_e dx
-            const int u = 1 + t / NW, i = t - (u - 1) * NW;
+        WG_WAVE_SYNC();
+        WG_ITEM_FOR(q, i, d, NW) {      // r_e = -g_e + d nu_side - X_e dx
+            const int u = 1 + q;
             double *un = UN(u);
             double acc = -gval(un, u, i, wk) + sm[W::DNU + side_of(u) * NW + i];
             if (i < 2 * N) {
@@ -868,12 +894,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             }
             un[W::RV + i] = acc;
         }
-        WG_SYNC();
-        WG_STAMP(38);
-        WG_CONE() cone_step(2, dt_slot, wk);
-        WG_FOR(t, d * NW) {      // d w_e = B_e r_e
-            const int u = 1 + t / NW, i = t - (u - 1) * NW;
-            double *un = UN(u);
+        WG_WAVE_SYNC();
+        WG_ITEM_FOR(q, i, d, NW) {      // d w_e = B_e r_e
+            double *un = UN(1 + q);
             double acc = 0;
 #pragma unroll
             for (int k = 0; k < NW; ++k) acc += un[W::B + i * NW + k] * un[W::RV + k];

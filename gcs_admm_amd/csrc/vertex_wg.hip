@@ -16,8 +16,16 @@ namespace {
 using namespace gcsadmm_k;
 using gcs_wg::WG_THREADS;
 
+// (the diagnostic timing build gets the whole register file: with its stamps the n = 6 instantiation would spill at 256 registers,
+//  and a spill next to the stamps' divergent branches is stored under a partial EXEC mask by this compiler -- measured: every
+//  n = 6 solve failed in that build; the product build has no scratch, tests/test_build.py checks that)
+#ifdef GCS_WG_TIMING
+#define GCS_WG_MIN_BLOCKS 1
+#else
+#define GCS_WG_MIN_BLOCKS (gcs_wg::WG_THREADS <= 256 ? 2 : 1)
+#endif
 template <int N, class T>
-__global__ __launch_bounds__(WG_THREADS, (gcs_wg::WG_THREADS <= 256 ? 2 : 1)) void vertex_wg_kernel(gcs_wg::WgArgs<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
+__global__ __launch_bounds__(WG_THREADS, GCS_WG_MIN_BLOCKS) void vertex_wg_kernel(gcs_wg::WgArgs<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (cb->status != GCSADMM_RUNNING) return;

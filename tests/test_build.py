@@ -1,0 +1,28 @@
+"""Properties of the compiled kernels that the design depends on, read from the compiler's resource remarks of the in-tree build
+(no GPU needed: hipcc cross-compiles gfx950)."""
+
+
+def test_no_kernel_uses_scratch():
+    """Every kernel of the library fits the register file: no scratch (spills).  Beyond the cost (round 1: 760 B / lane made the
+    vertex kernel HBM-bound on its own spills), this compiler places a spill next to a divergent branch under a partial EXEC mask
+    (seen in the diagnostic timing build of the n = 6 workgroup program: every solve failed), so scratch is a correctness risk."""
+    from gcs_admm_amd import build
+    res = build.kernel_resources()
+    names = " ".join(res)
+    for must in ("vertex_wg_kernelILi2E", "vertex_wg_kernelILi3E", "vertex_wg_kernelILi6E", "vertex_prox_kernelILi6E", "vertex_kernel",
+                 "edge_kernel", "halo_pack_kernel", "ball_kernel"):
+        assert must in names, must
+    bad = {k: v for k, v in res.items() if v.get("scratch", 0) != 0}
+    assert not bad, bad
+
+
+def test_workgroup_program_occupancy():
+    """registers of the workgroup program allow the residency DESIGN.md section 4 states: n = 2, 3 four wavefronts per SIMD or
+    more (<= 128 VGPRs), n = 6 two (<= 256)"""
+    from gcs_admm_amd import build
+    res = build.kernel_resources()
+    for k, v in res.items():
+        if "vertex_wg_kernelILi2E" in k or "vertex_wg_kernelILi3E" in k:
+            assert v["vgprs"] + v["agprs"] <= 128, (k, v)
+        if "vertex_wg_kernelILi6E" in k:
+            assert v["vgprs"] + v["agprs"] <= 256, (k, v)
