@@ -162,7 +162,7 @@ template <int N> struct WL {
                          BS = DNU + pad2(2 * NW), BSI = BS + pad2(2 * NW * NW), BXS = BSI + pad2(2 * NW * NW),
                          PIVS = BXS + pad2(2 * NW * NX), BG = PIVS + pad2(2 * NW), XBG = BG + pad2(2 * NW), XBX = XBG + pad2(2 * NX),
                          XS = XBX + pad2(2 * NX * NX), RP = XS + pad2(NX * N), VV = RP + pad2(2 * NW), WW = VV + pad2(2 * NW), M = WW + pad2(2 * NW),
-                         MINV = M + pad2(NB1 * NB1), PIVM = MINV + pad2(NB1 * NB1), RHS = PIVM + pad2(NB1), SOL = RHS + pad2(NB1),
+                         PIVM = M + pad2(NB1 * NB1), RHS = PIVM + pad2(NB1), SOL = RHS + pad2(NB1),
                          SOC = SOL + pad2(NB1), PQ = SOC + pad2(WSoc<N>::SIZE), PC = PQ + pad2(NX + NW), SC = PC + pad2(NX + NW), RED = SC + pad2(SC_N), FIXED = RED + 3 * 3 * WG_WAVES;
     // per-unit block (offsets from the unit's base); the three facet-row arrays (4m each) follow at ROWS
     static constexpr int P = 0, DW = P + pad2(NW), TG = DW + pad2(NW), TF = TG + pad2(NW), LB = TF + pad2(N), KB = LB + 2, DLB = KB + 2,
@@ -1020,10 +1020,12 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             }
             SC[SC_GT] = 1.0;
         }
-        // placement: K entries from thread 0, the K_yy tasks (longest loop) right behind them, the y-column tasks on the next
-        // wavefront boundary; the last wavefront is left to the cone thread where the task counts allow
-        const int nK_ = U * 2 * NS, sKyy_ = nK_ & (WG_THREADS - 1), sKy_ = ((nK_ + U + 63) & ~63) & (WG_THREADS - 1);
-        WG_FOR_AT(t, U * 2 * NS, 0) {          // entries of K_i and X_i (packed lower, both halves)
+        // placement: every kind starts on its own wavefront boundary (a wavefront that holds tasks of two kinds runs both loops
+        // back to back: with the K_yy tasks right behind the K entries the second wavefront was this region's critical path,
+        // 3 900 cycles; measured by duplicating one kind at a time)
+        Place pla;
+        const int sK_ = pla.at(U * 2 * NS), sKy_ = pla.at(U * 2 * N), sKyy_ = pla.at(U);
+        WG_FOR_AT(t, U * 2 * NS, sK_) {          // entries of K_i and X_i (packed lower, both halves)
             const int u = t / (2 * NS), q = t - u * (2 * NS), i = q / NS, pq = q - i * NS;
             double *un = UN(u);
             double *K = un + W::K, *X = un + W::X;
@@ -1185,11 +1187,18 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_SYNC();
         WG_STAMP(9);
         // ================= reduced border matrix in the (x, u, z2, y_v) variables =================
-        // step 1: every entry of the lower triangle in the (x, z1, z2, y_v) variables (into the MINV buffer, free until the
-        // inverse); step 2: the change of variables below needs up to four of them per entry
+        // One region: every entry of the lower triangle directly in the new variables.  The change of variables (u, z2) =
+        // (z1 - z2, z2) -- columns / rows of z2 gain those of z1; the cone term Su then sits on u alone (with the cone inactive
+        // Su ~ 1/mu would cancel in the (z1, z2) form) -- touches the zeta rows only, whose entries in the old variables are
+        // three-term sums (zx, zz below): an entry of the new matrix is at most four of them, summed in the order a two-step
+        // assembly through a scratch matrix would use (that was one more region: 2 200 cycles against ~1 400).
         {
             const double *YS0 = sm + W::BS, *YS1 = sm + W::BS + NW * NW, *u0 = UN(0);
-            double *MR = sm + W::MINV;
+            auto zx = [&](int i, int c) { return u0[W::X + i * NX + c] + YS0[i * NX + c] + YS1[i * NX + c]; };
+            auto zz = [&](int i, int k) {       // symmetric; the lower-triangle copy is the one used
+                const int hi = i > k ? i : k, lo = i > k ? k : i;
+                return u0[W::K + hi * NW + lo] + sm[W::BSI + hi * NW + lo] + sm[W::BSI + NW * NW + hi * NW + lo];
+            };
             Place plm;
             WG_FOR_AT(t, NX * (NX + 1) / 2, plm.at(NX * (NX + 1) / 2)) {        // x-x
                 int r, c;
@@ -1199,33 +1208,26 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll
                 for (int k = 0; k < NW; ++k)
                     val += sm[W::BXS + k * NX + r] * YS0[k * NX + c] + sm[W::BXS + NW * NX + k * NX + r] * YS1[k * NX + c];
-                MR[r * NB1 + c] = val;
+                sm[W::M + r * NB1 + c] = val;
             }
             WG_FOR_AT(t, NW * NX, plm.at(NW * NX)) {                            // zeta-x
                 const int i = t / NX, c = t - i * NX;
-                MR[(NX + i) * NB1 + c] = u0[W::X + i * NX + c] + YS0[i * NX + c] + YS1[i * NX + c];
+                double val = zx(i, c);
+                if (i >= N && i < 2 * N) val += zx(i - N, c);
+                sm[W::M + (NX + i) * NB1 + c] = val;
             }
             WG_FOR_AT(t, NW * (NW + 1) / 2, plm.at(NW * (NW + 1) / 2)) {        // zeta-zeta
                 int i, k;
                 tri_decode(t, i, k);
-                MR[(NX + i) * NB1 + NX + k] = u0[W::K + i * NW + k] + sm[W::BSI + i * NW + k] + sm[W::BSI + NW * NW + i * NW + k];
+                const bool rz2 = i >= N && i < 2 * N, cz2 = k >= N && k < 2 * N;
+                double val = zz(i, k);
+                if (cz2) val += zz(i, k - N);
+                if (rz2) val += zz(i - N, k);
+                if (rz2 && cz2) val += zz(i - N, k - N);
+                if (i < N && k < N) val += SOC[SO::SU + i * N + k];
+                sm[W::M + (NX + i) * NB1 + NX + k] = val;
             }
             rhs_tasks(plm, false);       // affine solve, head 4/4
-            WG_SYNC();
-            // change of variables (u, z2) = (z1 - z2, z2): columns / rows of z2 gain those of z1; the cone term Su then sits
-            // on u alone (with the cone inactive Su ~ 1/mu would cancel in the (z1, z2) form)
-            auto mr = [&](int r, int c) { return r >= c ? MR[r * NB1 + c] : MR[c * NB1 + r]; };
-            WG_FOR(t, NB1 * (NB1 + 1) / 2) {
-                int r, c;
-                tri_decode(t, r, c);
-                const bool rz2 = r >= NX + N && r < NX + 2 * N, cz2 = c >= NX + N && c < NX + 2 * N;
-                double val = MR[r * NB1 + c];
-                if (cz2) val += mr(r, c - N);
-                if (rz2) val += mr(r - N, c);
-                if (rz2 && cz2) val += mr(r - N, c - N);
-                if (r >= NX && r < NX + N && c >= NX && c < NX + N) val += SOC[SO::SU + (r - NX) * N + (c - NX)];
-                sm[W::M + r * NB1 + c] = val;
-            }
         }
         WG_SYNC();
         WG_STAMP(10);

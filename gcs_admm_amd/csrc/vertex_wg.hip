@@ -24,6 +24,14 @@ using gcs_wg::WG_THREADS;
 #else
 #define GCS_WG_MIN_BLOCKS (gcs_wg::WG_THREADS <= 256 ? 2 : 1)
 #endif
+// diagnostic builds: -DGCS_WG_TIMING = region stamps (vertex_wg.h) + whole-solve ticks per workgroup; -DGCS_WG_BLOCKTIME = the
+// whole-solve ticks alone (two s_memtime per solve: the low-overhead yardstick for A/B comparisons of the program)
+#if defined(GCS_WG_TIMING) && !defined(GCS_WG_BLOCKTIME)
+#define GCS_WG_BLOCKTIME 1
+#endif
+#ifdef GCS_WG_BLOCKTIME
+__device__ unsigned long long g_wg_block_ticks[64], g_wg_block_iters[64];
+#endif
 template <int N, class T>
 __global__ __launch_bounds__(WG_THREADS, GCS_WG_MIN_BLOCKS) void vertex_wg_kernel(gcs_wg::WgArgs<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
 {
@@ -39,10 +47,19 @@ __global__ __launch_bounds__(WG_THREADS, GCS_WG_MIN_BLOCKS) void vertex_wg_kerne
         return;
     }
     int status = 0, iters = 0;
+#ifdef GCS_WG_BLOCKTIME
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     gcs_wg::wg_solve_vertex<N, T>(a, a.vtx[blockIdx.x], rho, mu_scale, smem, status, iters);
     if (threadIdx.x == 0) {
         if (status != 0) atomicAdd(&a.counters[0], 1);
         atomicAdd(&a.counters[1], iters);
+#ifdef GCS_WG_BLOCKTIME
+        if (blockIdx.x < 64) {      // whole-solve ticks and Newton iterations of the first 64 workgroups (which one ends the launch?)
+            g_wg_block_ticks[blockIdx.x] += __builtin_amdgcn_s_memtime() - t_begin;
+            g_wg_block_iters[blockIdx.x] += (unsigned long long)iters;
+        }
+#endif
     }
 }
 
@@ -154,6 +171,14 @@ extern "C" int gcsadmm_debug_wg_cycles(unsigned long long *cycles64, unsigned lo
 {
     int e = (int)hipMemcpyFromSymbol(cycles64, HIP_SYMBOL(gcs_wg::g_wg_cycles), 64 * sizeof(unsigned long long));
     if (e == 0) e = (int)hipMemcpyFromSymbol(counts64, HIP_SYMBOL(gcs_wg::g_wg_counts), 64 * sizeof(unsigned long long));
+    return e;
+}
+#endif
+#ifdef GCS_WG_BLOCKTIME
+extern "C" int gcsadmm_debug_wg_blocks(unsigned long long *ticks64, unsigned long long *iters64)
+{
+    int e = (int)hipMemcpyFromSymbol(ticks64, HIP_SYMBOL(g_wg_block_ticks), 64 * sizeof(unsigned long long));
+    if (e == 0) e = (int)hipMemcpyFromSymbol(iters64, HIP_SYMBOL(g_wg_block_iters), 64 * sizeof(unsigned long long));
     return e;
 }
 #endif

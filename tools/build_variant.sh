@@ -1,0 +1,9 @@
+#!/bin/bash
+# builds tools/_exp/lib<name>.so from a copy of the sources: bash tools/build_variant.sh <name> <csrc dir> [extra flags]
+# (A/B experiments of the workgroup program with -DGCS_WG_BLOCKTIME; needs the regular build's gcsadmm.o / polytope_lp.o)
+set -e
+name=$1; src=$2; shift 2
+mkdir -p tools/_exp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$src -DGCS_WG_BLOCKTIME "$@" -c $src/vertex_wg.hip -o tools/_exp/$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC gcs_admm_amd/gcsadmm.o gcs_admm_amd/polytope_lp.o tools/_exp/$name.o -o tools/_exp/lib$name.so
+echo tools/_exp/lib$name.so

@@ -1,0 +1,38 @@
+"""A/B yardstick for the workgroup vertex program: whole-solve s_memtime ticks per workgroup (mean over launches) from a
+-DGCS_WG_BLOCKTIME build (two s_memtime reads per solve: far less intrusive than the region stamps).
+usage: python tools/wg_blocktime.py <lib.so> [<lib2.so> ...]      (development tool; builds: tools/build_variant.sh)"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from gcs_admm_amd import solver
+from gcs_admm_amd.cases import load_fixture
+from gcs_admm_amd.graph import lattice_boxes
+
+def run(lib, wl):
+    solver.LIB_PATH = os.path.abspath(lib); solver._lib = None
+    if wl == "benchmark4": g, dt = load_fixture("benchmark4")[1], "f64"
+    elif wl == "lat6": g, dt = lattice_boxes(16, 16, n=6, seed=0), "f32"
+    elif wl == "lat2": g, dt = lattice_boxes(16, 16, seed=0), "f32"
+    d = solver.DeviceSolver(g, dt, device=0, program="workgroup")
+    d.reset(max_it=100000, eps_abs=0.0, eps_rel=0.0)
+    bt = (C.c_ulonglong * 64)(); bi = (C.c_ulonglong * 64)()
+    d.enqueue(20); torch.cuda.synchronize()
+    d.lib.gcsadmm_debug_wg_blocks(bt, bi); t0, i0 = np.array(list(bt), float), np.array(list(bi), float)
+    steps = 200 if wl != "lat6" else 40
+    t = __import__("time").perf_counter(); d.enqueue(steps); torch.cuda.synchronize(); el = __import__("time").perf_counter() - t
+    d.lib.gcsadmm_debug_wg_blocks(bt, bi); t1, i1 = np.array(list(bt), float) - t0, np.array(list(bi), float) - i0
+    nb = min(64, d.query()["num_workgroup_vertices"])
+    t1, i1 = t1[:nb] / steps, i1[:nb] / steps
+    print(f"{os.path.basename(lib):28s} {wl:10s} ticks/solve: max {t1.max():8.0f} mean {t1.mean():8.0f}   per Newton iteration: mean {np.mean(t1 / i1):7.0f}   "
+          f"{steps / el:7.1f} it/s", flush=True)
+    if os.environ.get("WG_BLOCKTIME_TOP"):
+        vt = d.wg_vertices() if hasattr(d, "wg_vertices") else None
+        for b in np.argsort(-t1)[:int(os.environ["WG_BLOCKTIME_TOP"])]:
+            print(f"    workgroup {b:2d}: {t1[b]:8.0f} ticks, {i1[b]:5.2f} Newton iterations, {t1[b] / i1[b]:7.0f} ticks each", flush=True)
+
+libs = sys.argv[1:]
+for wl in ("benchmark4", "lat2", "lat6"):
+    for lib in libs:
+        run(lib, wl)

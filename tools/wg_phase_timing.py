@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from gcs_admm_amd import solver
-solver.LIB_PATH = os.path.join(ROOT, "gcs_admm_amd", "libgcsadmm_timing.so")
+solver.LIB_PATH = os.path.abspath(os.environ.get("GCSADMM_TIMING_LIB", os.path.join(ROOT, "gcs_admm_amd", "libgcsadmm_timing.so")))
 from gcs_admm_amd.cases import load_fixture
 from gcs_admm_amd.graph import lattice_boxes
 
@@ -41,4 +41,16 @@ for wl in sys.argv[1:] or ["benchmark4", "lat6"]:
         if n1[k] > 0:
             print(f"  {k:2d} {NAMES[k]:32s} {100 * c1[k] / tot:6.2f} %   {c1[k] / n1[k]:9.1f} ticks/visit  x{n1[k] / steps:.1f}")
     res[wl] = dict(cycles=c1.tolist(), counts=n1.tolist(), steps=steps)
+    if hasattr(d.lib, "gcsadmm_debug_wg_blocks"):      # whole-solve ticks per workgroup: which vertex ends the launch?
+        bt = (C.c_ulonglong * 64)(); bi = (C.c_ulonglong * 64)()
+        d.lib.gcsadmm_debug_wg_blocks(bt, bi)
+        nb = min(64, d.query()["num_workgroup_vertices"])
+        tot_steps = steps + 10
+        bt, bi = np.array(list(bt), float)[:nb] / tot_steps, np.array(list(bi), float)[:nb] / tot_steps
+        deg = np.diff(g.inc_ptr); fac = np.diff(g.poly_ptr)
+        order = np.argsort(-bt)
+        print(f"  whole solve, ticks per launch (mean over {tot_steps} launches since the handle was created): max {bt.max():.0f}, median {np.median(bt):.0f}, workgroup 0 {bt[0]:.0f}")
+        for b in order[:6]:
+            print(f"    workgroup {b:2d}: {bt[b]:9.0f} ticks  {bi[b]:5.1f} Newton iterations  ({bt[b] / max(bi[b], 1):7.0f} ticks each)")
+        res[wl]["block_ticks"] = bt.tolist(); res[wl]["block_iters"] = bi.tolist()
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "wg_phase_timing.json"), "w"))
