@@ -666,10 +666,10 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     }
     int n_generic = 0;
     for (int v = 0; v < V; ++v) n_generic += !is_special(v);
-    // Crossover of the two programs on n = 2 (measured on box lattices, profiles/r02/README.md: 576 vertices 4 050 vs 3 050 it/s,
-    // 1 024 vertices 2 470 vs 2 940): up to ~768 generic vertices one workgroup per vertex is faster (latency: every region of
-    // a solve runs 256 threads wide), above it the wavefront program's packing of several vertices per wavefront wins.
-    constexpr int WG_AUTO_MAX = 768;
+    // Crossover of the two programs on n = 2 (measured on box lattices, profiles/r02/README.md: 1 024 vertices 3 570 vs 3 030 it/s,
+    // 1 444 vertices 2 410 vs 3 060): the workgroup program holds 4 workgroups per CU (102 registers), i.e. 1 024 vertices in one
+    // round of ~0.28 ms; the wavefront program packs up to 7 vertices per wavefront and serves up to ~7 000 in one round of 0.33 ms.
+    constexpr int WG_AUTO_MAX = 1024;
     if (g->vertex_program < 0 || g->vertex_program > 2) return fail(GCSADMM_ERR_BAD_ARG, "vertex_program must be 0, 1 or 2");
     const bool prefer_wg = g->vertex_program == 2 || (g->vertex_program == 0 && n_generic <= WG_AUTO_MAX);
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx, wg_vtx;

@@ -1091,13 +1091,92 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_STAMP(2);
         if (SC[SC_CONEFAIL] != 0.0) { status = mu <= 1e3 * a.ipm_tol ? 0 : -4; break; }
 
-        // ================= blocks: Cholesky, explicit inverse B_e, B_e X_e =================
-        wg_chol<NW>(UN(1) + W::K, UN(1) + W::PIV, d, US, US);
-        WG_STAMP(3);
-        WG_FOR(t, d * NW) {
-            const int u = 1 + t / NW, c = t - (u - 1) * NW;
+        // ================= blocks: explicit inverse B_e = K_e^{-1}, then B_e X_e =================
+        // K_e = [K1 0 k1; 0 K2 k2; k1' k2' kappa]: the two halves of O_e are coupled only through y_e, so the Cholesky factor
+        // in natural order is [L1 0 0; 0 L2 0; l1' l2' lambda] and the inverse has a closed form in the two N x N inverses:
+        //   w_h = K_h^{-1} k_h,  s = kappa - k1'w1 - k2'w2,
+        //   B = [K1^{-1} + w1 w1'/s   w1 w2'/s   -w1/s;   .   K2^{-1} + w2 w2'/s   -w2/s;   .   .   1/s].
+        // Region 1, one thread per (block, half): Cholesky of K_h, K_h^{-1}, w_h, k_h'w_h, all in registers (the pivots are those
+        // of the (2n+1)-dimensional factorisation: same clamp rule).  Region 2, one thread per entry: the rank-one term.
+        // (The generic tiled Cholesky + column solves of the whole block took 2 000 / 8 300 cycles at n = 2 / 6.)
+        WG_FOR(t, 2 * d) {
+            const int u = 1 + (t >> 1), h = t & 1;
             double *un = UN(u);
-            chol_inverse_col<NW>(un + W::K, un + W::PIV, c, un + W::B, NW);
+            double a[NS], li[NS], kv[N], pv[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                kv[i] = un[W::K + (h * N + i) * NW + 2 * N];
+#pragma unroll
+                for (int j = 0; j <= i; ++j) a[pki(i, j)] = un[W::K + (h * N + i) * NW + h * N + j];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {           // Cholesky, packed lower; a(i,j) becomes L(i,j), pv the inverse pivots
+                const double od = a[pki(j, j)];
+                double dj = od;
+#pragma unroll
+                for (int k = 0; k < j; ++k) dj -= a[pki(j, k)] * a[pki(j, k)];
+                if (!(dj > CHOL_SKIP * od)) dj = od > 0.0 ? CHOL_SKIP * od : 1.0;
+                const double inv = rsqrt_nr(dj);
+                pv[j] = inv;
+#pragma unroll
+                for (int i = j + 1; i < N; ++i) {
+                    double sij = a[pki(i, j)];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) sij -= a[pki(i, k)] * a[pki(j, k)];
+                    a[pki(i, j)] = sij * inv;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < N; ++c)             // L^{-1}, lower
+#pragma unroll
+                for (int i = c; i < N; ++i) {
+                    double sx = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = c; k < i; ++k) sx -= a[pki(i, k)] * li[pki(k, c)];
+                    li[pki(i, c)] = sx * pv[i];
+                }
+#pragma unroll
+            for (int r = 0; r < N; ++r)             // K_h^{-1} = L^{-T} L^{-1}, stored (both triangles) into the half's block of B
+#pragma unroll
+                for (int c = 0; c <= r; ++c) {
+                    double acc = 0;
+#pragma unroll
+                    for (int i = r; i < N; ++i) acc += li[pki(i, r)] * li[pki(i, c)];
+                    un[W::B + (h * N + r) * NW + h * N + c] = acc;
+                    un[W::B + (h * N + c) * NW + h * N + r] = acc;
+                }
+            // l = L^{-1} k_h (the y row of the factor), k_h' K_h^{-1} k_h = |l|^2 exactly as the Cholesky pivot forms it (through the
+            // explicit inverse the Schur complement s loses cond(K_h) instead of its square root), w_h = L^{-T} l
+            double lv[N], ch = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double acc = 0;
+#pragma unroll
+                for (int c = 0; c <= i; ++c) acc += li[pki(i, c)] * kv[c];
+                lv[i] = acc;
+                ch += acc * acc;
+            }
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                double acc = 0;
+#pragma unroll
+                for (int i = r; i < N; ++i) acc += li[pki(i, r)] * lv[i];
+                un[W::PIV + h * N + r] = acc;
+            }
+            un[W::RV + h] = ch;
+        }
+        WG_SYNC();
+        WG_STAMP(3);
+        WG_FOR(t, d * NW * NW) {
+            const int u = 1 + t / (NW * NW), ij = t - (u - 1) * (NW * NW), i = ij / NW, j = ij - i * NW;
+            double *un = UN(u);
+            const double kap = un[W::K + 2 * N * NW + 2 * N];
+            double sy = kap - un[W::RV] - un[W::RV + 1];
+            if (!(sy > CHOL_SKIP * kap)) sy = kap > 0.0 ? CHOL_SKIP * kap : 1.0;
+            const double rs = rcp(sy);
+            const double wi = i < 2 * N ? un[W::PIV + i] : -1.0, wj = j < 2 * N ? un[W::PIV + j] : -1.0;
+            const double base = (i < 2 * N && j < 2 * N && i / N == j / N) ? un[W::B + ij] : 0.0;
+            un[W::B + ij] = base + wi * wj * rs;
         }
         WG_SYNC();
         WG_STAMP(4);
@@ -1251,6 +1330,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             rmax = fmax(rmax, fmax(-q, 1.0 + q));
             c1 += s * dl + l * ds; c2 += ds * dl;
             un[oR1 + ro] = ds * dl;
+            un[oR2 + ro] = is;           // kappa = (sigma mu - ds_a dl_a) / s is formed where it is used (G'kappa, final direction)
         }
         WG_FOR_AT(u, U, plb.at(U)) {
             double *un = UN(u);
@@ -1276,22 +1356,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             sig = sig * sig * sig;
             sigmu = sig * mu;
         }
-        // ================= corrector: kappa = (sigma mu - ds_a dl_a) / s per row, cone part by thread 0 =================
-        Place plk;
-        WG_FOR_AT(r, RT, plk.at(RT)) {
-            int u, ro, ty, i, j;
-            row_decode(r, u, ro, ty, i, j);
-            double *un = UN(u);
-            un[oR2 + ro] = (sigmu - un[oR1 + ro]) * rcp1(row_slack(un, ty, i, j));
-        }
-        WG_FOR_AT(u, U, plk.at(U)) {
-            double *un = UN(u);
-            const double yy = un[W::P + 2 * N];
-            un[W::KB] = (sigmu - un[W::KB]) * rcp1(yy);
-            un[W::KB + 1] = (sigmu - un[W::KB + 1]) * rcp1(1.0 - yy);
-        }
-        WG_SYNC();
-        WG_STAMP(15);
+        // ================= corrector: kappa = (sigma mu - ds_a dl_a) / s per row; cone part by the cone thread =================
+        // (no region of its own for the row kappas: both factors are in the row arrays since the pass above -- the reduction's
+        //  barrier published them -- and sigma mu is known to every thread)
         WG_CONE() {   // (beside the G'kappa tasks: the last wavefront has none) kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) )
             double wb[Q], a1[Q], a2[Q], pr[Q], qv[Q], xs[Q], lt[Q], ss[Q];
             const double eta = SC[SC_ETA];
@@ -1326,28 +1393,29 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_FOR_AT(t, U * 2 * N, plg.at(U * 2 * N)) {
             const int u = t / (2 * N), q = t - u * (2 * N), i = q / N, k = q - i * N;
             double *un = UN(u);
-            const double *ka = un + oR2, *kb = ka + m2;
+            const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
             double s = 0;
 #pragma unroll 4
-            for (int j = 0; j < m; ++j) s += A[j * N + k] * (ka[i * m + j] - kb[i * m + j]);
+            for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - ea[i * m + j]) * ia[i * m + j] - (sigmu - eb[i * m + j]) * ib[i * m + j]);
             un[W::GU + q] = s;
         }
         WG_FOR_AT(t, U * NX, plg.at(U * NX)) {
             const int u = t / NX, c = t - u * NX, i = c / N, k = c - i * N;
             double *un = UN(u);
-            const double *kb = un + oR2 + m2;
+            const double *eb = un + oR1 + m2, *ib = un + oR2 + m2;
             double s = 0;
 #pragma unroll 4
-            for (int j = 0; j < m; ++j) s += A[j * N + k] * kb[i * m + j];
+            for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - eb[i * m + j]) * ib[i * m + j]);
             un[W::GX + c] = s;
         }
         WG_FOR_AT(u, U, plg.at(U)) {
             double *un = UN(u);
-            const double *ka = un + oR2, *kb = ka + m2;
+            const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
             double s = 0;
 #pragma unroll 4
-            for (int j = 0; j < m2; ++j) s += BC[j >= m ? j - m : j] * (kb[j] - ka[j]);
-            un[W::GU + 2 * N] = s - un[W::KB] + un[W::KB + 1];
+            for (int j = 0; j < m2; ++j) s += BC[j >= m ? j - m : j] * ((sigmu - eb[j]) * ib[j] - (sigmu - ea[j]) * ia[j]);
+            const double yy = un[W::P + 2 * N];
+            un[W::GU + 2 * N] = s - (sigmu - un[W::KB]) * rcp1(yy) + (sigmu - un[W::KB + 1]) * rcp1(1.0 - yy);
         }
         WG_SYNC();
         WG_STAMP(16);
@@ -1364,7 +1432,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const double s = row_slack(un, ty, i, j), l = un[oLAM + ro];
             const double ip = rcp1(s * l), is = l * ip, il = s * ip;      // 1/s and 1/l from one reciprocal
             const double ds = row_ds(un, ty, i, j);
-            const double dl = un[oR2 + ro] - l - (l * is) * ds;
+            const double dl = (sigmu - un[oR1 + ro]) * un[oR2 + ro] - l - (l * is) * ds;      // kappa - l - (l / s) ds
             un[oR2 + ro] = dl;
             rmax = fmax(rmax, fmax(-ds * is, -dl * il));
         }
@@ -1373,7 +1441,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const double yy = un[W::P + 2 * N], dy = un[W::DW + 2 * N];
             const double s5 = yy, s6 = 1.0 - yy, l5 = un[W::LB], l6 = un[W::LB + 1];
             const double i5 = rcp1(s5), i6 = rcp1(s6);
-            const double dl5 = un[W::KB] - l5 - l5 * i5 * dy, dl6 = un[W::KB + 1] - l6 + l6 * i6 * dy;
+            const double dl5 = (sigmu - un[W::KB]) * i5 - l5 - l5 * i5 * dy, dl6 = (sigmu - un[W::KB + 1]) * i6 - l6 + l6 * i6 * dy;
             un[W::DLB] = dl5; un[W::DLB + 1] = dl6;
             rmax = fmax(rmax, fmax(fmax(-dy * i5, -dl5 * rcp1(l5)), fmax(dy * i6, -dl6 * rcp1(l6))));
         }

@@ -17,8 +17,8 @@ def test_no_kernel_uses_scratch():
 
 
 def test_workgroup_program_occupancy():
-    """registers of the workgroup program allow the residency DESIGN.md section 4 states: n = 2, 3 four wavefronts per SIMD or
-    more (<= 128 VGPRs), n = 6 two (<= 256)"""
+    """registers of the workgroup program allow the residency DESIGN.md section 4 states (and the auto rule of gcsadmm_create
+    relies on: 4 workgroups per CU at n = 2): n = 2, 3 four wavefronts per SIMD or more (<= 128 VGPRs), n = 6 two (<= 256)"""
     from gcs_admm_amd import build
     res = build.kernel_resources()
     for k, v in res.items():

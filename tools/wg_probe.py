@@ -68,6 +68,11 @@ if "box" in which:      # box specialisation of the wavefront program against it
         for dt in ("f32", "f64"):
             rate(f"lat{nx}x{ny}_m4", g, "wavefront", dt, steps=60, warm=5, wave_generic_rows=2)
             rate(f"lat{nx}x{ny}_box", g, "wavefront", dt, steps=60, warm=5)
+if "cross" in which:    # crossover of the two programs on n = 2 box lattices (WG_AUTO_MAX in gcsadmm_create)
+    for (nx, ny) in ((24, 24), (28, 28), (32, 32), (38, 38), (45, 45), (64, 64)):
+        g = lattice_boxes(nx, ny, seed=0)
+        for prog in ("workgroup", "wavefront"):
+            rate(f"lat{nx}x{ny}", g, prog, "f32", steps=100, warm=10)
 if "small" in which:
     case, g4 = load_fixture("benchmark4")
     rate("benchmark4", g4, "workgroup", "f64", steps=300, warm=20)
