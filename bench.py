@@ -82,6 +82,21 @@ def cpu_baseline(g, workload, seconds=20.0):
                       f"best thread count of a sweep up to {ncpu})"}
 
 
+def measured_traffic(workload, family):
+    """HBM bytes per launch of a kernel family ("vertex" / "edge") of this workload.  PMC counters cannot be read from inside this
+    process: the figure is the one rocprofv3 collected for this same command line (separate --pmc passes, tools/profile_round.sh ->
+    profiles/r02), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, KB -> bytes.  (None, None) when no profile of
+    the workload is committed."""
+    prof = os.path.join(PROFILE_DIR, f"{workload}_hbm_counters.json")
+    if not os.path.exists(prof):
+        return None, None
+    pc = json.load(open(prof))
+    kk = next((k for k in pc.get("FETCH_SIZE", {}) if k == family or (family == "edge" and k.startswith("edge"))), None)
+    if not kk or kk not in pc.get("WRITE_SIZE", {}):
+        return None, None
+    return 1024.0 * (2.0 * pc["FETCH_SIZE"][kk]["mean_KB_per_launch"] + pc["WRITE_SIZE"][kk]["mean_KB_per_launch"]), os.path.relpath(prof, ROOT)
+
+
 def counted_flops(g):
     """f64 operations of ONE vertex step from the zero state, counted (not modelled): the workgroup program's source
     compiled for the host with a counting scalar type (tools/flopcount), add / mul = 1, fma = 2, division and square root
@@ -161,17 +176,7 @@ def main():
         alg_bytes = g.algorithmic_bytes_per_iteration(wb)
         ach = alg_bytes / (v_ms * 1e-3) / 1e9
         kernel = {"workgroup": f"vertex_wg_kernel<{g.n}>", "wavefront": "vertex_kernel<2>", "mixed": "vertex_kernel<2> + vertex_wg_kernel<2>"}[program]
-        traffic, traffic_src = None, None
-        prof = os.path.join(PROFILE_DIR, f"{args.workload}_hbm_counters.json")
-        if os.path.exists(prof):
-            # PMC counters cannot be read from inside this process: the per-launch figure is the one rocprofv3 collected for
-            # this same command line (separate --pmc passes, profiles/r02), FETCH_SIZE doubled as MI355X_MICROARCH.md
-            # prescribes for gfx950, KB -> bytes
-            pc = json.load(open(prof))
-            kk = next((k for k in pc.get("FETCH_SIZE", {}) if k.startswith("vertex")), None)
-            if kk and kk in pc.get("WRITE_SIZE", {}):
-                traffic = 1024.0 * (2.0 * pc["FETCH_SIZE"][kk]["mean_KB_per_launch"] + pc["WRITE_SIZE"][kk]["mean_KB_per_launch"])
-                traffic_src = os.path.relpath(prof, ROOT)
+        traffic, traffic_src = measured_traffic(args.workload, {"workgroup": "vertex_wg_kernel", "wavefront": "vertex_kernel"}.get(program, "-"))
         cb_ = dev.read_control()
         n_generic = g.num_vertices - q["num_special"]
         it_per_vertex = cb_.inner_iters / max(n_generic, 1)
@@ -194,12 +199,16 @@ def main():
                                   "note": "COUNTED f64 operations of the vertex step (tools/flopcount: the workgroup program's source "
                                           "compiled for the host with a counting scalar; add/mul = 1, fma = 2), scaled to this "
                                           "window's Newton iterations per vertex"}
-        # the streaming half of the iteration on its own (edge average + dual + residual sums + control,
-        # 14 c |E| words), HBM-bound once the state outgrows the caches
-        edge_bytes = 14.0 * g.c * g.num_edges * wb
+        # the streaming half of the iteration on its own (edge average + dual + residual sums + control).  Bytes of THIS layout:
+        # read 2 copies + 2 mu + zedge (5c), write zedge + 2 mu (3c) -- targets are never stored, so this is
+        # below the 10c words SURVEY 8(d) budgets for an edge kernel that writes them.  HBM-bound once the state outgrows the caches.
+        edge_bytes = 8.0 * g.c * g.num_edges * wb
         out["roofline_edge"] = {"bound": "hbm", "achieved": edge_bytes / (e_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": edge_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "edge_kernel (+finalize/control)",
-                                "avg_step_ms": e_ms, "algorithmic_bytes_per_step": edge_bytes}
+                                "frac": edge_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "edge_kernel (one launch: averages, duals, norms, control)",
+                                "avg_step_ms": e_ms, "algorithmic_bytes_per_step": edge_bytes,
+                                "traffic": measured_traffic(args.workload, "edge")[0],
+                                "note": "the head-side copy / mu columns of an edge are gathered (incidence-major state): measured traffic is "
+                                        "2-3x the algorithmic bytes (DESIGN.md section 4, edge_kernel)"}
         # ---- matched convergence: the reference's own stop rule ----
         if args.workload == "benchmark4" and not args.loop_only:
             res = dev.solve(timed=True)
@@ -208,6 +217,7 @@ def main():
                                   "cost": res["cost"], "reference_cost": gold["cost"],
                                   "classic_cost": extra["case"]["golden_classic"]["cost"],
                                   "solve_time_s": res["device_time_s"], "loop_wall_time_s": res["wall_time_s"],
+                                  "iterations_per_sec_to_stop": res["iterations"] / max(res["wall_time_s"], 1e-12),
                                   "reference_solve_time_s": gold["solve_time"]}
             # iterations-to-eps (the second half of BASELINE.json's metric): eps_abs = eps_rel = 1e-6, MAX_IT lifted;
             # the relaxation optimum the monolithic solve reports (classic_solver record) is the yardstick
