@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="benchmark4", choices=["benchmark4", "s10k", "s100k", "s6d"])
     ap.add_argument("--program", default="auto", choices=["auto", "wavefront", "workgroup"])
+    ap.add_argument("--columns", default="auto", choices=["auto", "incidence", "edge"],
+                    help="numbering of the state columns (include/gcsadmm.h edge_major_columns); auto = edge-major from 20 000 edges")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--partition-timeout", type=int, default=240, help="seconds the sharded S100k leg may take at N > 1 before the line is printed without it")
     ap.add_argument("--loop-only", action="store_true",
@@ -133,7 +135,8 @@ def main():
     from gcs_admm_amd.solver import DeviceSolver
 
     g, dtype, extra = make_workload(args.workload)
-    dev = DeviceSolver(g, dtype, device=local, program=args.program)
+    columns = args.columns if args.columns != "auto" else ("edge" if g.num_edges >= 20000 else "incidence")
+    dev = DeviceSolver(g, dtype, device=local, program=args.program, columns=columns)
     q = dev.query()
     program = "workgroup" if q["num_workgroup_vertices"] and not q["num_waves"] else ("wavefront" if not q["num_workgroup_vertices"] else "mixed")
     # fixed-length timing window: the stop test is disabled (eps = 0) so that exactly K iterations run
@@ -156,7 +159,7 @@ def main():
            "dtype": "f64" if dtype == "f64" else "f64 (interior point) on f32 state",
            "data": "synthetic" if args.workload != "benchmark4" else "fixture of the reference's test_data/benchmark4.py",
            "config": {"workload": args.workload, "V": g.num_vertices, "E": g.num_edges, "n": g.n,
-                      "state_dtype": dtype, "inner_arithmetic": "f64", "ipm_tol": 1e-9, "vertex_program": program,
+                      "state_dtype": dtype, "state_columns": columns, "inner_arithmetic": "f64", "ipm_tol": 1e-9, "vertex_program": program,
                       "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (the workload does not shard; "
                                                                   "the sharded path is in partitioned_s100k)",
                       "seed": None if args.workload == "benchmark4" else 0,
@@ -207,8 +210,9 @@ def main():
                                 "frac": edge_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "edge_kernel (one launch: averages, duals, norms, control)",
                                 "avg_step_ms": e_ms, "algorithmic_bytes_per_step": edge_bytes,
                                 "traffic": measured_traffic(args.workload, "edge")[0],
-                                "note": "the head-side copy / mu columns of an edge are gathered (incidence-major state): measured traffic is "
-                                        "2-3x the algorithmic bytes (DESIGN.md section 4, edge_kernel)"}
+                                "state_columns": columns,
+                                "note": "edge-major columns make this kernel a pure stream; with incidence-major columns the head-side "
+                                        "columns of an edge are gathers (2-3x the algorithmic bytes measured, DESIGN.md section 4)"}
         # ---- matched convergence: the reference's own stop rule ----
         if args.workload == "benchmark4" and not args.loop_only:
             res = dev.solve(timed=True)
@@ -253,7 +257,7 @@ def main():
             gl = lattice_boxes(316, 317, seed=0)
             psteps, pwarm = min(args.steps, 100), min(args.warmup, 10)
             pparams = dict(max_it=psteps + pwarm + 1, eps_abs=0.0, eps_rel=0.0)
-            part, pdev = device_partition(gl, rank, world, "f32", device=local)
+            part, pdev = device_partition(gl, rank, world, "f32", device=local, columns="edge")
         except Exception as exc:
             ok, block = 0.0, {"error": f"rank {rank}: {type(exc).__name__}: {exc}"}
         if world > 1:      # every rank learns whether ALL ranks are ready before the first collective of this leg
@@ -278,7 +282,7 @@ def main():
                          "collectives_per_iteration": "1 grouped send/recv per neighbour + 1 all-reduce of 6 f64",
                          "path": "gcsadmm_run_partitioned (C ABI, RCCL on the caller's stream, no host synchronisation)"}
                 if world > 1:      # the same lattice on one GPU, same loop: the strong-scaling reference
-                    sdev = DeviceSolver(gl, "f32", device=local)
+                    sdev = DeviceSolver(gl, "f32", device=local, columns="edge")
                     sel = time_loop(sdev, psteps, pwarm, pparams)
                     block["single_gpu_iterations_per_sec"] = psteps / sel
                     block["speedup_vs_1gpu"] = sel / pel

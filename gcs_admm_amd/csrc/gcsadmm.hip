@@ -130,7 +130,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
     const double mu_scale = cb->mu_scale;
     double s[5] = {0, 0, 0, 0, 0};
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.E; e += gridDim.x * blockDim.x) {
-        const int it = a.edge_inc_tail[e], ih = a.edge_inc_head[e];
+        // edge-major columns (null index arrays): the two columns of edge e are e and E + e, every access below is a stream
+        const int it = a.edge_inc_tail ? a.edge_inc_tail[e] : e, ih = a.edge_inc_head ? a.edge_inc_head[e] : a.E + e;
         const double we = a.edge_counted ? (double)a.edge_counted[e] : 1.0;
         const double wt = a.inc_counted ? (double)a.inc_counted[it] : 1.0;
         const double wh = a.inc_counted ? (double)a.inc_counted[ih] : 1.0;
@@ -293,6 +294,8 @@ struct gcsadmm_handle_s {
     int n = 0, V = 0, E = 0, NI = 0, NI_owned = 0, c = 0, MM = 0, dtype = 0, device = 0;
     int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
     int n_wg = 0, wg_lds_bytes = 0;   // vertices solved by the workgroup program (vertex_wg.hip), LDS per workgroup
+    int edge_major = 0;       // state columns numbered by edge (gcsadmm_graph_desc.edge_major_columns)
+    std::vector<char> col_owned;   // [NI] 1: the column of an incidence of this handle's vertices, 0: a ghost column
     int all_m4 = 0;           // 1: every wavefront-program vertex has exactly 4 facets -> the register-dual program; 2: and all are canonical boxes
     int align_rows = 0;       // group placement rule (group_base)
     int store_dl = 0;         // LDS holds the final dual directions of the facet rows (kernel template SDL)
@@ -433,7 +436,7 @@ static WgLaunchDesc make_wg_desc(gcsadmm_handle h, const gcsadmm_state *st, bool
     d.vtx = h->d_wg_vtx; d.special_vtx = h->d_special_vtx; d.special_kind = h->d_special_kind;
     d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
     d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
-    d.E = h->E; d.NI = h->NI;
+    d.E = h->E; d.NI = h->NI; d.edge_major = h->edge_major;
     d.zedge = st->zedge; d.mu = st->mu; d.copy = st->copy; d.xv = st->xv; d.zv = st->zv; d.yv = st->yv;
     d.counters = h->d_counters; d.cb = h->d_cb;
     d.eps_edge = h->params.eps_edge; d.ipm_tol = h->params.ipm_tol; d.ipm_max_iter = h->params.ipm_max_iter;
@@ -459,7 +462,8 @@ template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcs
     const gcsadmm_params &pp = h->params;
     const ControlParams cp{pp.tau_incr, pp.tau_decr, pp.nu, pp.eps_abs, pp.eps_rel, h->nx, h->nmu, pp.it_rho_limit, pp.max_it};
     EdgeArgs<T> a;
-    a.E = h->E; a.NI = h->NI; a.c = h->c; a.edge_inc_tail = h->d_edge_inc_tail; a.edge_inc_head = h->d_edge_inc_head;
+    a.E = h->E; a.NI = h->NI; a.c = h->c;
+    a.edge_inc_tail = h->edge_major ? nullptr : h->d_edge_inc_tail; a.edge_inc_head = h->edge_major ? nullptr : h->d_edge_inc_head;
     a.inc_counted = h->d_inc_counted; a.edge_counted = h->d_edge_counted;
     a.copy = (const T *)st->copy; a.zedge = (T *)st->zedge; a.mu = (T *)st->mu; a.partials = h->d_partials;
     // one kernel instantiation per (state type, mode, words per copy)
@@ -493,7 +497,7 @@ static VertexLaunchDesc make_launch_desc(gcsadmm_handle h, const gcsadmm_state *
     d.wave_slot_ptr = h->d_wave_slot_ptr; d.wave_vtx = h->d_wave_vtx; d.special_vtx = h->d_special_vtx; d.special_kind = h->d_special_kind;
     d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
     d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
-    d.E = h->E; d.NI = h->NI; d.MM = h->MM;
+    d.E = h->E; d.NI = h->NI; d.MM = h->MM; d.edge_major = h->edge_major;
     d.zedge = st->zedge; d.mu = st->mu; d.copy = st->copy; d.xv = st->xv; d.zv = st->zv; d.yv = st->yv;
     d.counters = h->d_counters; d.cb = h->d_cb;
     d.eps_edge = h->params.eps_edge; d.ipm_tol = h->params.ipm_tol; d.ipm_max_iter = h->params.ipm_max_iter;
@@ -517,8 +521,9 @@ static gcsadmm_status halo_upload(gcsadmm_handle h, const gcsadmm_halo_desc *hd)
         for (int j = 0; j < cnt; ++j) { sbase[lo + j] = lo * c + j; sstride[lo + j] = cnt; }     // block of peer p: [c][cnt] at lo * c
     }
     for (int j = 0; j < h->n_send; ++j) {
-        if (hd->send_cols[j] < 0 || hd->send_cols[j] >= h->NI_owned) { h->err = "halo lists: send column is not an owned incidence"; return GCSADMM_ERR_BAD_ARG; }
-        if (hd->recv_cols[j] < h->NI_owned || hd->recv_cols[j] >= h->NI) { h->err = "halo lists: receive column is not a ghost column"; return GCSADMM_ERR_BAD_ARG; }
+        if (hd->send_cols[j] < 0 || hd->send_cols[j] >= h->NI || hd->recv_cols[j] < 0 || hd->recv_cols[j] >= h->NI) { h->err = "halo lists: column out of range"; return GCSADMM_ERR_BAD_ARG; }
+        if (!h->col_owned[hd->send_cols[j]]) { h->err = "halo lists: send column is not an owned incidence"; return GCSADMM_ERR_BAD_ARG; }
+        if (h->col_owned[hd->recv_cols[j]]) { h->err = "halo lists: receive column is not a ghost column"; return GCSADMM_ERR_BAD_ARG; }
     }
     const size_t esz = h->dtype == GCSADMM_F64 ? 8 : 4;
     HIPCHK(h, upload(&h->d_send_cols, hd->send_cols, (size_t)h->n_send));
@@ -628,6 +633,13 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         if (g->edge_inc_tail[e] < 0 || g->edge_inc_tail[e] >= g->num_incidences || g->edge_inc_head[e] < 0 ||
             g->edge_inc_head[e] >= g->num_incidences)
             return fail(GCSADMM_ERR_BAD_ARG, "edge incidence slot out of range");
+    if (g->edge_major_columns != 0 && g->edge_major_columns != 1) return fail(GCSADMM_ERR_BAD_ARG, "edge_major_columns must be 0 or 1");
+    if (g->edge_major_columns) {
+        if (g->num_incidences != 2 * (int64_t)E) return fail(GCSADMM_ERR_BAD_ARG, "edge-major columns: num_incidences must be 2 num_edges");
+        for (int e = 0; e < E; ++e)
+            if (g->edge_inc_tail[e] != e || g->edge_inc_head[e] != E + e)
+                return fail(GCSADMM_ERR_BAD_ARG, "edge-major columns: edge_inc_tail[e] must be e and edge_inc_head[e] num_edges + e");
+    }
 
     // centred right-hand sides b - A c
     const int MT = g->poly_ptr[V];
@@ -759,6 +771,11 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     auto *h = new (std::nothrow) gcsadmm_handle_s;
     if (!h) return fail(GCSADMM_ERR_HIP, "out of host memory");
     h->n = n; h->V = V; h->E = E; h->NI = g->num_incidences; h->NI_owned = NIo; h->c = 2 * n + 1; h->MM = MM;
+    h->edge_major = g->edge_major_columns;
+    h->col_owned.assign((size_t)std::max<int64_t>(g->num_incidences, 1), 0);
+    for (int v = 0; v < V; ++v)
+        for (int k = g->inc_ptr[v]; k < g->inc_ptr[v + 1]; ++k)
+            h->col_owned[h->edge_major ? g->inc_edge[k] + (g->inc_out[k] ? 0 : E) : k] = 1;
     h->dtype = g->state_dtype; h->device = g->device;
     h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
     h->slots_cap = std::max(1, max_slots_used);

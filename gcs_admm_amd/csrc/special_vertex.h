@@ -23,6 +23,7 @@ template <class T> struct SpecialArgs {
     T *copy;
     double *xv, *zv, *yv;
     double eps_edge;
+    int edge_major = 0;     // 1: state columns numbered by edge (tail side e, head side E + e) instead of by incidence
 };
 
 // vals / u: work arrays of MAX_SPECIAL_DEG doubles each, used by the source and the target only
@@ -35,7 +36,7 @@ __device__ void special_body(const SpecialArgs<T> &a, int i, double rho, double 
 #pragma unroll
     for (int k = 0; k < N; ++k) cen[k] = a.center[(size_t)v * N + k];
     auto target = [&](int w, int k) -> double {
-        const int inc = lo + k, e = a.inc_edge[inc];
+        const int e = a.inc_edge[lo + k], inc = a.edge_major ? e + (k >= d_in ? 0 : a.E) : lo + k;
         return (double)a.zedge[(size_t)w * a.E + e] - mu_scale * (double)a.mu[(size_t)w * a.NI + inc];
     };
     const bool is_src = kind == 1, is_dst = kind == 2;
@@ -72,7 +73,7 @@ __device__ void special_body(const SpecialArgs<T> &a, int i, double rho, double 
         double ye = 0.0;
         if (live) { ye = vals[e - live_lo] - tau; ye = ye > 0 ? ye : 0.0; }
         const bool outgoing = e >= d_in;
-        const int inc = lo + e;
+        const int inc = a.edge_major ? a.inc_edge[lo + e] + (outgoing ? 0 : a.E) : lo + e;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const double yc = (kind != 0) ? ye * cen[k] : 0.0;

@@ -20,7 +20,7 @@ struct VertexLaunchDesc {
     const int *wave_slot_ptr, *wave_vtx, *special_vtx, *special_kind;
     const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
     const double *poly_A, *poly_bc, *center;
-    int E, NI, MM;
+    int E, NI, MM, edge_major;
     void *zedge, *mu, *copy;
     double *xv, *zv, *yv;
     int *counters;
@@ -210,12 +210,12 @@ template <class PROG, int N, class T> static void launch_vertex_prog(const Verte
     a.E = d.E; a.NI = d.NI; a.MM = d.MM;
     a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
     a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
-    a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter;
+    a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter; a.edge_major = d.edge_major;
     SpecialArgs<T> sp;
     sp.count = d.n_special; sp.vtx = d.special_vtx; sp.kind = d.special_kind;
     sp.inc_ptr = d.inc_ptr; sp.deg_in = d.deg_in; sp.inc_edge = d.inc_edge; sp.center = d.center;
     sp.E = d.E; sp.NI = d.NI; sp.zedge = (const T *)d.zedge; sp.mu = (const T *)d.mu; sp.copy = (T *)d.copy;
-    sp.xv = d.xv; sp.zv = d.zv; sp.yv = d.yv; sp.eps_edge = d.eps_edge;
+    sp.xv = d.xv; sp.zv = d.zv; sp.yv = d.yv; sp.eps_edge = d.eps_edge; sp.edge_major = d.edge_major;
     const unsigned grid = (unsigned)(d.n_waves + (d.n_special + WAVE - 1) / WAVE);
     const int lds = std::max(d.lds_bytes, (int)(4 * MAX_SPECIAL_DEG * sizeof(double)));   // room for the special work arrays
 #define GCS_LAUNCH(RM, DL) hipLaunchKernelGGL((vertex_kernel<PROG, N, T, RM, DL>), dim3(grid), dim3(WAVE), lds, s, a, sp, d.cb)

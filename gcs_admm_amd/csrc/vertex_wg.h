@@ -200,6 +200,7 @@ template <class T> struct WgArgs {
     // no edge blocks; a separable quadratic 1/2 sum_k q_k (u_k - c_k)^2 on the border unknowns u = (x_v, z_v, y_v) instead of
     // the consensus penalty.  [V][4n+1] each, order x (2n), z (2n), y; nullptr = the ADMM vertex step of the v3 solver.
     const double *prox_q = nullptr, *prox_c = nullptr;
+    int edge_major = 0;         // 1: state columns numbered by edge (tail side e, head side E + e) instead of by incidence
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -652,10 +653,11 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     // ---- load: polytope, targets, start point (strictly feasible, as oracle_solve_vertex) ----
     Place pl0;
     WG_FOR_AT(t, d * NW, pl0.at(d * NW)) {
-        const int e = t / NW, w = t - e * NW, inc = lo + e, edge = a.inc_edge[inc];
+        const int e = t / NW, w = t - e * NW, edge = a.inc_edge[lo + e];
+        const bool out = e >= d_in;
+        const int inc = a.edge_major ? edge + (out ? 0 : a.E) : lo + e;      // state column of this incidence
         double *un = UN(e + 1);
         const double Tw = (double)a.zedge[(size_t)w * a.E + edge] - mu_scale * (double)a.mu[(size_t)w * a.NI + inc];
-        const bool out = e >= d_in;
         // block targets: T1 (of O[:n]), T2 (of O[n:], outgoing only), Ty; the first word of an incoming edge is free
         if (w == 2 * N) un[W::TG + 2 * N] = Tw;
         else if (out) un[W::TG + w] = Tw;
@@ -1499,8 +1501,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     // ---- un-centre and write out ----
     Place plo;
     WG_FOR_AT(t, d * NW, plo.at(d * NW)) {
-        const int e = t / NW, w = t - e * NW, inc = lo + e;
+        const int e = t / NW, w = t - e * NW;
         const bool out = e >= d_in;
+        const int inc = a.edge_major ? a.inc_edge[lo + e] + (out ? 0 : a.E) : lo + e;
         const double *un = UN(e + 1), *p = un + W::P;
         const double yy = p[2 * N];
         double val;

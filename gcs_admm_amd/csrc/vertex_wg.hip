@@ -72,12 +72,12 @@ template <int N, class T> void launch(const WgLaunchDesc &d, hipStream_t s)
     a.E = d.E; a.NI = d.NI;
     a.zedge = (const T *)d.zedge; a.mu = (const T *)d.mu; a.copy = (T *)d.copy;
     a.xv = d.xv; a.zv = d.zv; a.yv = d.yv; a.counters = d.counters;
-    a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter;
+    a.eps_edge = d.eps_edge; a.ipm_tol = d.ipm_tol; a.ipm_max_iter = d.ipm_max_iter; a.edge_major = d.edge_major;
     SpecialArgs<T> sp;
     sp.count = d.n_special; sp.vtx = d.special_vtx; sp.kind = d.special_kind;
     sp.inc_ptr = d.inc_ptr; sp.deg_in = d.deg_in; sp.inc_edge = d.inc_edge; sp.center = d.center;
     sp.E = d.E; sp.NI = d.NI; sp.zedge = (const T *)d.zedge; sp.mu = (const T *)d.mu; sp.copy = (T *)d.copy;
-    sp.xv = d.xv; sp.zv = d.zv; sp.yv = d.yv; sp.eps_edge = d.eps_edge;
+    sp.xv = d.xv; sp.zv = d.zv; sp.yv = d.yv; sp.eps_edge = d.eps_edge; sp.edge_major = d.edge_major;
     const unsigned grid = (unsigned)(d.n_vtx + (d.n_special + WG_THREADS - 1) / WG_THREADS);
     if (grid == 0) return;
     const int lds = std::max(d.lds_bytes, (int)(4 * MAX_SPECIAL_DEG * sizeof(double)));

@@ -14,7 +14,7 @@ struct WgLaunchDesc {
     const int *special_vtx, *special_kind;   // trailing workgroups (may be empty: n_special = 0)
     const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
     const double *poly_A, *poly_bc, *center;
-    int E, NI;
+    int E, NI, edge_major;
     void *zedge, *mu, *copy;
     double *xv, *zv, *yv;
     int *counters;

@@ -43,7 +43,7 @@ class GraphDesc(C.Structure):
                 ("nx_global", C.c_double), ("nmu_global", C.c_double),
                 # schedule of the vertex step (0 = automatic): see include/gcsadmm.h
                 ("vertex_program", C.c_int32), ("wave_slots", C.c_int32), ("wave_align", C.c_int32),
-                ("wave_store_dl", C.c_int32), ("wave_generic_rows", C.c_int32), ("reserved0", C.c_int32)]
+                ("wave_store_dl", C.c_int32), ("wave_generic_rows", C.c_int32), ("edge_major_columns", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -121,12 +121,18 @@ class DeviceSolver:
     a partition, ``num_incidences`` > ``inc_ptr[-1]`` adds ghost copy slots and
     ``inc_counted`` / ``edge_counted`` implement the ownership rule of the
     global norms.
+
+    ``columns``: numbering of the state columns of ``copy`` / ``mu``.  "incidence" (default): column k = position k of
+    the vertex CSR, the numbering ``graph`` and every per-column argument (``inc_counted``, halo lists) are written in.
+    "edge": tail side of edge e in column e, head side in column E + e -- the edge step becomes a pure stream (the layout for
+    large graphs, include/gcsadmm.h ``edge_major_columns``).  Arguments stay in incidence numbering either way; ``col_of``
+    maps an incidence column to the state column, and ``copy[:, col_of]`` is the state in incidence order.
     """
 
     def __init__(self, graph: GcsGraph, state_dtype: str = "f64", device: Optional[int] = None,
                  num_incidences: Optional[int] = None, inc_counted=None, edge_counted=None,
                  nx_global: float = 0.0, nmu_global: float = 0.0, program: str = "auto", wave_slots: int = 0,
-                 wave_align: int = 0, wave_store_dl: int = 0, wave_generic_rows: int = 0):
+                 wave_align: int = 0, wave_store_dl: int = 0, wave_generic_rows: int = 0, columns: str = "incidence"):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the ADMM loop only runs on the GPU (no CPU fallback)")
@@ -140,9 +146,25 @@ class DeviceSolver:
         g = graph
         ni_owned = int(g.inc_ptr[-1])
         self.NI = int(num_incidences) if num_incidences is not None else ni_owned
+        if columns not in ("incidence", "edge"):
+            raise ValueError("columns must be 'incidence' or 'edge'")
+        self.edge_major = columns == "edge"
+        tail, head = g.edge_inc_tail.astype(np.int32), g.edge_inc_head.astype(np.int32)
+        self.col_of = np.arange(self.NI, dtype=np.int64)          # incidence column -> state column
+        if self.edge_major:
+            E_ = g.num_edges
+            if self.NI != 2 * E_:
+                raise ValueError("edge-major columns need exactly two columns per edge")
+            self.col_of = np.empty(self.NI, dtype=np.int64)
+            self.col_of[tail] = np.arange(E_); self.col_of[head] = E_ + np.arange(E_)
+            tail, head = np.arange(E_, dtype=np.int32), (E_ + np.arange(E_)).astype(np.int32)
+            if inc_counted is not None:
+                ic_new = np.empty(self.NI, dtype=np.uint8)
+                ic_new[self.col_of] = np.asarray(inc_counted, dtype=np.uint8)
+                inc_counted = ic_new
         self._keep = [np.ascontiguousarray(a) for a in (
             g.inc_ptr.astype(np.int32), g.inc_edge.astype(np.int32), g.inc_out.astype(np.int32),
-            g.edge_inc_tail.astype(np.int32), g.edge_inc_head.astype(np.int32), g.poly_ptr.astype(np.int32),
+            tail, head, g.poly_ptr.astype(np.int32),
             g.poly_A.astype(np.float64), g.poly_b.astype(np.float64), g.interior.astype(np.float64))]
         k = self._keep
         ic = np.ascontiguousarray(inc_counted, dtype=np.uint8) if inc_counted is not None else None
@@ -154,7 +176,7 @@ class DeviceSolver:
                          _np_ptr(ic) if ic is not None else None, _np_ptr(ec) if ec is not None else None,
                          float(nx_global), float(nmu_global),
                          {"auto": 0, "wavefront": 1, "workgroup": 2}[program], int(wave_slots), int(wave_align),
-                         int(wave_store_dl), int(wave_generic_rows), 0)
+                         int(wave_store_dl), int(wave_generic_rows), int(self.edge_major))
         h = C.c_void_p()
         st = self.lib.gcsadmm_create(C.byref(desc), C.byref(h))
         if st != 0:
@@ -258,6 +280,8 @@ class DeviceSolver:
     def attach_comm(self, rank: int, world: int, unique_id, send_idx, recv_idx):
         """Join the communicator (collective) and upload this partition's halo lists.  ``unique_id`` None: world 1 only."""
         peers, ptr, sc, rc = halo_arrays(send_idx, recv_idx)
+        if self.edge_major:      # the lists are written in incidence columns
+            sc = np.ascontiguousarray(self.col_of[sc].astype(np.int32)); rc = np.ascontiguousarray(self.col_of[rc].astype(np.int32))
         self._halo_keep = (peers, ptr, sc, rc)
         hd = HaloDesc(len(peers), _np_ptr(peers), _np_ptr(ptr), _np_ptr(sc), _np_ptr(ptr), _np_ptr(rc))
         idb = (C.c_ubyte * 128).from_buffer_copy(unique_id) if unique_id is not None else None

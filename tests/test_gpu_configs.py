@@ -238,10 +238,12 @@ def test_partitioned_loop_behind_the_abi_single_rank(torch_gpu):
     assert np.array_equal(a.zedge.cpu().numpy(), b.zedge.cpu().numpy())
 
 
-def test_halo_pack_unpack_two_handles(torch_gpu):
+@pytest.mark.parametrize("columns", ["incidence", "edge"])
+def test_halo_pack_unpack_two_handles(torch_gpu, columns):
     """the pack / unpack kernels and halo lists of the C ABI with the transfer done by hand: two partitions of one lattice
     as two handles on this GPU; packed send buffers are copied device-to-device into the peer's receive buffer (what
-    ncclSend / ncclRecv do across GPUs), then unpacked into the ghost columns.  Against the single handle."""
+    ncclSend / ncclRecv do across GPUs), then unpacked into the ghost columns.  Against the single handle.  Both column
+    numberings of the state (edge-major: the ghost of a cut edge is the column of its remote side)."""
     torch = torch_gpu
     import ctypes as C
     import os
@@ -254,7 +256,7 @@ def test_halo_pack_unpack_two_handles(torch_gpu):
     owner = strip_owner(g, 2)
     parts = [build_partition(g, owner, r, 2) for r in range(2)]
     devs = [DeviceSolver(p.graph, "f32", device=0, num_incidences=p.num_incidences, inc_counted=p.inc_counted,
-                         edge_counted=p.edge_counted, nx_global=p.nx_global, nmu_global=p.nmu_global) for p in parts]
+                         edge_counted=p.edge_counted, nx_global=p.nx_global, nmu_global=p.nmu_global, columns=columns) for p in parts]
     for r, (p, d) in enumerate(zip(parts, devs)):
         d.attach_comm(r, 2, None, p.send_idx, p.recv_idx)
         d.reset(max_it=60)
@@ -279,3 +281,39 @@ def test_halo_pack_unpack_two_handles(torch_gpu):
         assert np.allclose(d.zedge.cpu().numpy(), full[:, p.edge_global], rtol=0, atol=5e-4)
     cbs = [d.read_control() for d in devs] + [single.read_control()]
     assert len({cb.it for cb in cbs}) == 1 and len({cb.status for cb in cbs}) == 1
+
+
+@pytest.mark.parametrize("case", ["benchmark4", "lattice_wave", "lattice_wg", "lattice_r6", "star"])
+def test_edge_major_columns_equal_incidence_major(torch_gpu, case):
+    """include/gcsadmm.h edge_major_columns: the numbering of the state columns changes where a value lives, never the value --
+    the same runs in both numberings are BITWISE equal (vertex programs compute the same solves, the edge kernel handles edge e
+    in thread e either way, the norms are summed in the same order), for both vertex programs, the closed-form vertices, n = 6."""
+    torch = torch_gpu
+    from conftest import star_case
+    from gcs_admm_amd.cases import load_fixture
+    from gcs_admm_amd.graph import graph_from_sets
+    from gcs_admm_amd.solver import DeviceSolver
+    kw, dt, its = {}, "f64", 30
+    if case == "benchmark4":
+        g = load_fixture("benchmark4")[1]
+    elif case == "lattice_wave":
+        g, kw, dt = lattice_boxes(40, 30, seed=3), dict(program="wavefront"), "f32"
+    elif case == "lattice_wg":
+        g, kw = lattice_boxes(12, 9, seed=3), dict(program="workgroup")
+    elif case == "lattice_r6":
+        g, dt, its = lattice_boxes(7, 6, n=6, seed=2), "f32", 8
+    else:
+        As, bs, n = star_case(24)
+        g, its = graph_from_sets(As, bs, n), 10
+    a = DeviceSolver(g, dt, device=0, **kw)
+    b = DeviceSolver(g, dt, device=0, columns="edge", **kw)
+    assert not a.edge_major and b.edge_major and sorted(b.col_of.tolist()) == list(range(2 * g.num_edges))
+    for d in (a, b):
+        d.reset(max_it=its + 5)
+        d.enqueue(its)
+    torch.cuda.synchronize()
+    perm = torch.from_numpy(b.col_of).to("cuda")
+    assert torch.equal(a.copy, b.copy[:, perm]) and torch.equal(a.mu, b.mu[:, perm]) and torch.equal(a.zedge, b.zedge)
+    assert torch.equal(a.xv, b.xv) and torch.equal(a.zv, b.zv) and torch.equal(a.yv, b.yv)
+    assert torch.equal(a.trace[:its], b.trace[:its]) and a.read_control().it == b.read_control().it == its + 1
+    assert float(a.copy.abs().max()) > 0.0
