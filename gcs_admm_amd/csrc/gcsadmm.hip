@@ -120,7 +120,9 @@ __global__ void control_kernel(gcsadmm_control_block *cb, const double *sums, Co
 // MODE 1: single workgroup (at most EDGE_BLOCK edges, gcsadmm_run on small graphs): the workgroup also does the final
 //         reduction and the control step;
 // MODE 2: any grid (gcsadmm_run): the LAST workgroup to finish -- told by an agent-scope ticket counter -- reduces all the
-//         partials in the fixed order of finalize_kernel and runs the control step: one launch per edge step instead of two.
+//         partials in the fixed order of finalize_kernel and runs the control step: one launch per edge step instead of two;
+// MODE 3: as MODE 2 without the control step (gcsadmm_run_partitioned): the last workgroup leaves the five sums and, in
+//         sums[5], this partition's inner-failure count for the all-reduce that follows.
 // C = coupled words per copy (2n+1), compile-time so that all C x 5 loads of an edge are in flight at once.
 template <class T, int MODE, int C>
 __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm_control_block *cb, double *sums, ControlParams cp,
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
     if (threadIdx.x < 5) {
         double t = 0;
         for (int q = 0; q < EDGE_BLOCK / WAVE; ++q) t += red[q][threadIdx.x];
-        if (MODE == 2) __hip_atomic_store(&a.partials[(size_t)blockIdx.x * 5 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE >= 2) __hip_atomic_store(&a.partials[(size_t)blockIdx.x * 5 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
         if (MODE == 1) sums[threadIdx.x] = t;      // one workgroup: its partial is the sum (what finalize_kernel would produce)
     }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
         __syncthreads();
         if (threadIdx.x == 0) control_body(cb, sums, cp, counters, trace);
     }
-    if (MODE == 2) {
+    if (MODE >= 2) {
         // hand-off of the partials to the last workgroup (MI355X_MICROARCH.md, inter-workgroup visibility): write-through (sc1)
         // stores by the first wavefront, drained, then ONE agent-scope ticket add by a lane of that same wavefront; the
         // workgroup whose add returns gridDim.x - 1 came last and reads every partial with sc1 loads.
@@ -207,7 +209,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
         if (threadIdx.x < 5) sums[threadIdx.x] = red[0][threadIdx.x];
         __syncthreads();
         if (threadIdx.x == 0) {
-            control_body(cb, sums, cp, counters, trace);
+            if (MODE == 2) control_body(cb, sums, cp, counters, trace);
+            else sums[5] = (double)counters[0];
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
         }
     }
@@ -254,13 +257,6 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(int c, int ncols, int 
     const int w = t / ncols, j = t - w * ncols;
     copy[(size_t)w * NI + cols[j]] = buf[base[j] + w * stride[j]];
 }
-// sums[5] := this partition's inner-failure count (summed with the norms by the all-reduce)
-__global__ void fails_to_sums_kernel(double *sums, const int *counters, const gcsadmm_control_block *cb)
-{
-    if (cb->status != GCSADMM_RUNNING) return;
-    if (threadIdx.x == 0 && blockIdx.x == 0) sums[5] = (double)counters[0];
-}
-
 template <class T>
 __global__ __launch_bounds__(256) void cost_kernel(int V, int E, int n, const double *zv, const T *zedge,
                                                    const uint8_t *edge_counted, double eps_edge, double *cost)
@@ -457,7 +453,7 @@ template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const g
 
 // with_control: the control step rides in the same launches (gcsadmm_run); trace may be null
 template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcsadmm_state *st, double *sums, hipStream_t s,
-                                                     bool with_control = false, double *trace = nullptr)
+                                                     bool with_control = false, double *trace = nullptr, bool sums6 = false)
 {
     const gcsadmm_params &pp = h->params;
     const ControlParams cp{pp.tau_incr, pp.tau_decr, pp.nu, pp.eps_abs, pp.eps_rel, h->nx, h->nmu, pp.it_rho_limit, pp.max_it};
@@ -473,7 +469,8 @@ template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcs
         if (h->c == 5) GCS_EDGE(5); else if (h->c == 7) GCS_EDGE(7); else GCS_EDGE(13);
 #undef GCS_EDGE
     };
-    if (with_control && h->edge_blocks == 1) go(std::integral_constant<int, 1>(), 1);
+    if (sums6) go(std::integral_constant<int, 3>(), h->edge_blocks);
+    else if (with_control && h->edge_blocks == 1) go(std::integral_constant<int, 1>(), 1);
     else if (with_control) go(std::integral_constant<int, 2>(), h->edge_blocks);
     else {
         go(std::integral_constant<int, 0>(), h->edge_blocks);
@@ -985,9 +982,9 @@ gcsadmm_status gcsadmm_run_partitioned(gcsadmm_handle h, const gcsadmm_state *st
         gcsadmm_status r;
         if ((r = gcsadmm_vertex_step(h, st, stream)) != GCSADMM_OK) return r;
         if ((r = gcsadmm_halo_exchange(h, st, stream)) != GCSADMM_OK) return r;
-        r = h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, h->d_sums6, s) : launch_edge<float>(h, st, h->d_sums6, s);
+        r = h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, h->d_sums6, s, false, nullptr, true)
+                                    : launch_edge<float>(h, st, h->d_sums6, s, false, nullptr, true);      // sums + failure count, one launch
         if (r != GCSADMM_OK) return r;
-        hipLaunchKernelGGL(fails_to_sums_kernel, dim3(1), dim3(1), 0, s, h->d_sums6, h->d_counters, h->d_cb);
         if (!h->comm && h->world > 1) { h->err = "gcsadmm_run_partitioned needs a communicator (gcsadmm_attach_comm with an id)"; return GCSADMM_ERR_BAD_ARG; }
         if (h->comm) NCCLCHK(h, rccl().AllReduce(h->d_sums6, h->d_sums6, 6, ncclFloat64, ncclSum, (ncclComm_t)h->comm, s));
         hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, s, h->d_cb, h->d_sums6, cp, h->d_counters, trace_dev, true);
