@@ -43,6 +43,7 @@ __device__ __forceinline__ void gcs_stamp(int k)
 #endif
 #include "vertex_kernel.h"
 #include "vertex_wg_launch.h"
+#include "canonical_box.h"
 
 namespace {
 
@@ -312,6 +313,7 @@ struct gcsadmm_handle_s {
     int n = 0, V = 0, E = 0, NI = 0, NI_owned = 0, c = 0, MM = 0, dtype = 0, device = 0;
     int n_waves = 0, n_special = 0, slots_cap = 0, lds_bytes = 0, edge_blocks = 0;
     int n_wg = 0, wg_lds_bytes = 0;   // vertices solved by the workgroup program (vertex_wg.hip), LDS per workgroup
+    int wg_box = 0;           // every workgroup-program vertex is a canonical box: BOX instantiation of that program
     int edge_unroll = 1;      // edges in flight per thread of the edge kernel
     int edge_major = 0;       // state columns numbered by edge (gcsadmm_graph_desc.edge_major_columns)
     std::vector<char> col_owned;   // [NI] 1: the column of an incidence of this handle's vertices, 0: a ghost column
@@ -455,7 +457,7 @@ static WgLaunchDesc make_wg_desc(gcsadmm_handle h, const gcsadmm_state *st, bool
     d.vtx = h->d_wg_vtx; d.special_vtx = h->d_special_vtx; d.special_kind = h->d_special_kind;
     d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
     d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
-    d.E = h->E; d.NI = h->NI; d.edge_major = h->edge_major;
+    d.E = h->E; d.NI = h->NI; d.edge_major = h->edge_major; d.box = h->wg_box;
     d.zedge = st->zedge; d.mu = st->mu; d.copy = st->copy; d.xv = st->xv; d.zv = st->zv; d.yv = st->yv;
     d.counters = h->d_counters; d.cb = h->d_cb;
     d.eps_edge = h->params.eps_edge; d.ipm_tol = h->params.ipm_tol; d.ipm_max_iter = h->params.ipm_max_iter;
@@ -709,6 +711,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx, wg_vtx;
     std::vector<char> on_wave(V, 0);
     int wg_lds = 0, MMw = 1;
+    bool wg_all_box = g->wave_generic_rows == 0;      // (the knob that forces the generic wavefront variants forces this one too)
     bool all_m4 = (n == 2) && g->wave_generic_rows != 1, all_box = all_m4 && g->wave_generic_rows != 2;
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v];
@@ -720,15 +723,12 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         } else if (n != 2 || d + 1 > WAVE || prefer_wg) {
             wg_vtx.push_back(v);
             wg_lds = std::max(wg_lds, gcsadmm_wg_lds_bytes(n, d + 1, m));
+            if (wg_all_box && !canonical_box(n, m, g->poly_A + (size_t)g->poly_ptr[v] * n)) wg_all_box = false;
         } else {
             on_wave[v] = 1;
             MMw = std::max(MMw, m);
             if (m != 4) all_m4 = false;
-            if (all_m4 && all_box) {   // facet normals exactly [+e0, +e1, -e0, -e1]
-                static const double canon[8] = {1, 0, 0, 1, -1, 0, 0, -1};
-                const double *A = g->poly_A + (size_t)g->poly_ptr[v] * 2;
-                for (int k = 0; k < 8; ++k) if (A[k] != canon[k]) all_box = false;
-            }
+            if (all_m4 && all_box && !canonical_box(2, m, g->poly_A + (size_t)g->poly_ptr[v] * 2)) all_box = false;   // [+e0, +e1, -e0, -e1]
         }
     }
     if (wg_lds > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "a vertex sub-problem (degree x facets) does not fit the 160 KB of LDS of a CU");
@@ -811,7 +811,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     }
     h->store_dl = store_dl;
     h->lds_bytes = n_waves > 0 ? (int)lds_need(h->slots_cap) : 0;
-    h->n_wg = (int)wg_vtx.size(); h->wg_lds_bytes = wg_lds;
+    h->n_wg = (int)wg_vtx.size(); h->wg_lds_bytes = wg_lds; h->wg_box = (wg_all_box && !wg_vtx.empty()) ? 1 : 0;
     h->nx = g->nx_global > 0 ? g->nx_global : (4.0 * n + 1) * (V + 2.0 * E);
     h->nmu = g->nmu_global > 0 ? g->nmu_global : (4.0 * n + 2) * E;
     {

@@ -623,7 +623,12 @@ template <int Q> GCS_HD void soc_apply_W2(const double *wb, double eta, const do
 // one vertex sub-problem.  `sm` is the workgroup's LDS (wg_lds_doubles doubles).  Returns (to every thread) the
 // solver status (0 = converged) and the number of interior-point iterations through status_out / iters_out.
 // ---------------------------------------------------------------------------------------------------------------
-template <int N, class T>
+// BOX: the vertex's polytope is an axis-aligned box with its facets in the canonical order [+e_0 .. +e_{N-1}, -e_0 .. -e_{N-1}] (the
+// lattice configurations; checked by the caller, canonical_box.h).  Facet j then has the single non-zero entry sg_j = +-1 at
+// k_j = j mod N: every facet-row dot product is one term, K_h and the x-coupling X_e of a unit are DIAGONAL (plus the y row /
+// column), and the loops over facets / coordinates below shrink accordingly.  Same algorithm, same operation order on the terms
+// that remain (the dropped terms are exact zeros), so results agree with the generic instantiation to rounding of -0.0 + x.
+template <int N, class T, bool BOX = false>
 GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_scale, double *sm, int &status_out, int &iters_out)
 {
     using D = WD<N>;
@@ -703,16 +708,28 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     // is what decides how many workgroups a CU holds at n = 6): s_a = b y - a.p_i ; s_b = b (1 - y) - a.(x_i - p_i)
     auto row_slack = [&](const double *un, int ty, int i, int j) {
         double ap = 0, ax = 0;
+        if constexpr (BOX) {
+            const int k = j >= N ? j - N : j;
+            ap = j >= N ? -un[W::P + i * N + k] : un[W::P + i * N + k];
+            ax = j >= N ? -sm[W::XV + i * N + k] : sm[W::XV + i * N + k];
+        } else {
 #pragma unroll
-        for (int k = 0; k < N; ++k) { ap += A[j * N + k] * un[W::P + i * N + k]; ax += A[j * N + k] * sm[W::XV + i * N + k]; }
+            for (int k = 0; k < N; ++k) { ap += A[j * N + k] * un[W::P + i * N + k]; ax += A[j * N + k] * sm[W::XV + i * N + k]; }
+        }
         const double yy = un[W::P + 2 * N], b = BC[j];
         return ty == 0 ? b * yy - ap : b * (1.0 - yy) - (ax - ap);
     };
     // slack direction of a row for the direction (DW of its unit, DX): ds_a = b dy - a.dp_i ; ds_b = -b dy - a.(dx_i - dp_i)
     auto row_ds = [&](const double *un, int ty, int i, int j) {
         double adp = 0, adx = 0;
+        if constexpr (BOX) {
+            const int k = j >= N ? j - N : j;
+            adp = j >= N ? -un[W::DW + i * N + k] : un[W::DW + i * N + k];
+            adx = j >= N ? -sm[W::DX + i * N + k] : sm[W::DX + i * N + k];
+        } else {
 #pragma unroll
-        for (int k = 0; k < N; ++k) { adp += A[j * N + k] * un[W::DW + i * N + k]; adx += A[j * N + k] * sm[W::DX + i * N + k]; }
+            for (int k = 0; k < N; ++k) { adp += A[j * N + k] * un[W::DW + i * N + k]; adx += A[j * N + k] * sm[W::DX + i * N + k]; }
+        }
         const double bdy = BC[j] * un[W::DW + 2 * N];
         return ty == 0 ? bdy - adp : -bdy - (adx - adp);
     };
@@ -757,8 +774,11 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll 2
             for (int u = ulo; u <= uhi; ++u) {
                 const double *un = UN(u);
+                if constexpr (BOX) acc += un[W::X + c * NX + c] * un[W::TE + c];
+                else {
 #pragma unroll
-                for (int k = 0; k < N; ++k) acc += un[W::X + (h * N + k) * NX + c] * un[W::TE + h * N + k];
+                    for (int k = 0; k < N; ++k) acc += un[W::X + (h * N + k) * NX + c] * un[W::TE + h * N + k];
+                }
                 acc += un[W::X + 2 * N * NX + c] * un[W::TE + 2 * N];
             }
             sm[W::XBG + t] = acc;
@@ -887,9 +907,12 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             double *un = UN(u);
             double acc = -gval(un, u, i, wk) + sm[W::DNU + side_of(u) * NW + i];
             if (i < 2 * N) {
-                const int h = i / N;
+                if constexpr (BOX) acc -= un[W::X + i * NX + i] * sm[W::DX + i];
+                else {
+                    const int h = i / N;
 #pragma unroll
-                for (int k = 0; k < N; ++k) acc -= un[W::X + i * NX + h * N + k] * sm[W::DX + h * N + k];
+                    for (int k = 0; k < N; ++k) acc -= un[W::X + i * NX + h * N + k] * sm[W::DX + h * N + k];
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < NX; ++c) acc -= un[W::X + i * NX + c] * sm[W::DX + c];
@@ -1037,11 +1060,18 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             if constexpr (N == 2) { k = pq > 0; l = pq > 1; }      // packed lower index of a 2 x 2 block: (0,0) (1,0) (1,1)
             else tri_decode(pq, k, l);
             double sk = 0, sx = 0;
+            if constexpr (BOX) {
+                if (k == l) {          // facets k and k + N carry e_k e_k'; every other product is zero
+                    sk = (Da[i * m + k] + Db[i * m + k]) + (Da[i * m + k + N] + Db[i * m + k + N]);
+                    sx = Db[i * m + k] + Db[i * m + k + N];
+                }
+            } else {
 #pragma unroll 4
-            for (int j = 0; j < m; ++j) {
-                const double aa = A[j * N + k] * A[j * N + l];
-                sk += (Da[i * m + j] + Db[i * m + j]) * aa;
-                sx += Db[i * m + j] * aa;
+                for (int j = 0; j < m; ++j) {
+                    const double aa = A[j * N + k] * A[j * N + l];
+                    sk += (Da[i * m + j] + Db[i * m + j]) * aa;
+                    sx += Db[i * m + j] * aa;
+                }
             }
             if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; if (prox) sk += sm[W::PQ + NX + i * N + k]; }
             K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
@@ -1056,11 +1086,17 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const double *Da = un + oR1, *Db = Da + m2;
             const bool blk = u > 0, out = blk && side_of(u);
             double sk = 0, sx = 0;
+            if constexpr (BOX) {
+                const double bp = BC[k], bn = -BC[k + N];       // b_j a_j[k] of the two facets on coordinate k
+                sk = -((Da[i * m + k] + Db[i * m + k]) * bp) - (Da[i * m + k + N] + Db[i * m + k + N]) * bn;
+                sx = Db[i * m + k] * bp + Db[i * m + k + N] * bn;
+            } else {
 #pragma unroll 4
-            for (int j = 0; j < m; ++j) {
-                const double ba = BC[j] * A[j * N + k];
-                sk -= (Da[i * m + j] + Db[i * m + j]) * ba;
-                sx += Db[i * m + j] * ba;
+                for (int j = 0; j < m; ++j) {
+                    const double ba = BC[j] * A[j * N + k];
+                    sk -= (Da[i * m + j] + Db[i * m + j]) * ba;
+                    sx += Db[i * m + j] * ba;
+                }
             }
             if (blk && (i == 0 || out)) sk += rho * CEN[k];
             if (prox) sk += sm[W::PQ + NX + i * N + k] * CEN[k];
@@ -1104,6 +1140,20 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_FOR(t, 2 * d) {
             const int u = 1 + (t >> 1), h = t & 1;
             double *un = UN(u);
+            if constexpr (BOX) {        // K_h is diagonal: its inverse, w_h = K_h^{-1} k_h and k_h'w_h entry by entry
+                double ch = 0;
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    const double dd = un[W::K + (h * N + r) * NW + h * N + r], kr = un[W::K + (h * N + r) * NW + 2 * N];
+                    const double inv = rsqrt_nr(dd), lr = kr * inv;       // (the pivot of a diagonal block is its entry: no clamp can fire)
+#pragma unroll
+                    for (int c = 0; c < N; ++c) un[W::B + (h * N + r) * NW + h * N + c] = c == r ? inv * inv : 0.0;
+                    un[W::PIV + h * N + r] = lr * inv;
+                    ch += lr * lr;
+                }
+                un[W::RV + h] = ch;
+                continue;
+            }
             double a[NS], li[NS], kv[N], pv[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -1187,8 +1237,11 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const int u = 1 + t / (NW * NX), ic = t - (u - 1) * (NW * NX), i = ic / NX, c = ic - i * NX, h = c / N;
             double *un = UN(u);
             double s = un[W::B + i * NW + 2 * N] * un[W::X + 2 * N * NX + c];
+            if constexpr (BOX) s += un[W::B + i * NW + c] * un[W::X + c * NX + c];       // X_e is diagonal in its x part
+            else {
 #pragma unroll
-            for (int k = 0; k < N; ++k) s += un[W::B + i * NW + h * N + k] * un[W::X + (h * N + k) * NX + c];
+                for (int k = 0; k < N; ++k) s += un[W::B + i * NW + h * N + k] * un[W::X + (h * N + k) * NX + c];
+            }
             un[W::K + ic] = s;
         }
         te_tasks(plx, false);            // affine solve, head 1/4
@@ -1217,8 +1270,11 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll 2
             for (int u = ulo; u <= uhi; ++u) {
                 const double *un = UN(u);
+                if constexpr (BOX) acc2 += un[W::X + r * NX + r] * un[W::K + r * NX + c];
+                else {
 #pragma unroll
-                for (int k = 0; k < N; ++k) acc2 += un[W::X + (h * N + k) * NX + r] * un[W::K + (h * N + k) * NX + c];
+                    for (int k = 0; k < N; ++k) acc2 += un[W::X + (h * N + k) * NX + r] * un[W::K + (h * N + k) * NX + c];
+                }
                 acc2 += un[W::X + 2 * N * NX + r] * un[W::K + 2 * N * NX + c];
             }
             sm[W::XBX + tp] = acc2;
@@ -1397,8 +1453,13 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             double *un = UN(u);
             const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
             double s = 0;
+            if constexpr (BOX) {
+                const int jp = i * m + k, jn = jp + N;
+                s = ((sigmu - ea[jp]) * ia[jp] - (sigmu - eb[jp]) * ib[jp]) - ((sigmu - ea[jn]) * ia[jn] - (sigmu - eb[jn]) * ib[jn]);
+            } else {
 #pragma unroll 4
-            for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - ea[i * m + j]) * ia[i * m + j] - (sigmu - eb[i * m + j]) * ib[i * m + j]);
+                for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - ea[i * m + j]) * ia[i * m + j] - (sigmu - eb[i * m + j]) * ib[i * m + j]);
+            }
             un[W::GU + q] = s;
         }
         WG_FOR_AT(t, U * NX, plg.at(U * NX)) {
@@ -1406,8 +1467,11 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             double *un = UN(u);
             const double *eb = un + oR1 + m2, *ib = un + oR2 + m2;
             double s = 0;
+            if constexpr (BOX) s = (sigmu - eb[i * m + k]) * ib[i * m + k] - (sigmu - eb[i * m + k + N]) * ib[i * m + k + N];
+            else {
 #pragma unroll 4
-            for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - eb[i * m + j]) * ib[i * m + j]);
+                for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - eb[i * m + j]) * ib[i * m + j]);
+            }
             un[W::GX + c] = s;
         }
         WG_FOR_AT(u, U, plg.at(U)) {

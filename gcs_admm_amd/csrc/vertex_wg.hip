@@ -32,7 +32,7 @@ using gcs_wg::WG_THREADS;
 #ifdef GCS_WG_BLOCKTIME
 __device__ unsigned long long g_wg_block_ticks[64], g_wg_block_iters[64];
 #endif
-template <int N, class T>
+template <int N, class T, bool BOX>
 __global__ __launch_bounds__(WG_THREADS, GCS_WG_MIN_BLOCKS) void vertex_wg_kernel(gcs_wg::WgArgs<T> a, SpecialArgs<T> sp, const gcsadmm_control_block *cb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(WG_THREADS, GCS_WG_MIN_BLOCKS) void vertex_wg_kerne
 #ifdef GCS_WG_BLOCKTIME
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-    gcs_wg::wg_solve_vertex<N, T>(a, a.vtx[blockIdx.x], rho, mu_scale, smem, status, iters);
+    gcs_wg::wg_solve_vertex<N, T, BOX>(a, a.vtx[blockIdx.x], rho, mu_scale, smem, status, iters);
     if (threadIdx.x == 0) {
         if (status != 0) atomicAdd(&a.counters[0], 1);
         atomicAdd(&a.counters[1], iters);
@@ -81,7 +81,12 @@ template <int N, class T> void launch(const WgLaunchDesc &d, hipStream_t s)
     const unsigned grid = (unsigned)(d.n_vtx + (d.n_special + WG_THREADS - 1) / WG_THREADS);
     if (grid == 0) return;
     const int lds = std::max(d.lds_bytes, (int)(4 * MAX_SPECIAL_DEG * sizeof(double)));
-    hipLaunchKernelGGL((vertex_wg_kernel<N, T>), dim3(grid), dim3(WG_THREADS), lds, s, a, sp, d.cb);
+    // the BOX instantiation pays from n = 3 (n = 6: -9 % per Newton iteration); at n = 2 the loops it shortens are two terms long and
+    // it measured 1 % slower, so n = 2 has none
+    if constexpr (N > 2) {
+        if (d.box) { hipLaunchKernelGGL((vertex_wg_kernel<N, T, true>), dim3(grid), dim3(WG_THREADS), lds, s, a, sp, d.cb); return; }
+    }
+    hipLaunchKernelGGL((vertex_wg_kernel<N, T, false>), dim3(grid), dim3(WG_THREADS), lds, s, a, sp, d.cb);
 }
 
 // PROX configuration (admm_solver_v1.py:334-383): one workgroup per vertex, no edge blocks; the two trailing
@@ -136,7 +141,10 @@ template <int N> void launch_prox(const WgLaunchDesc &d, const double *q, const 
 
 template <int N, class T> hipError_t set_lds(int lds_bytes)
 {
-    return hipFuncSetAttribute((const void *)vertex_wg_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void *)vertex_wg_kernel<N, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if constexpr (N > 2)
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)vertex_wg_kernel<N, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    return e;
 }
 
 }  // namespace

@@ -15,6 +15,7 @@ struct WgLaunchDesc {
     const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
     const double *poly_A, *poly_bc, *center;
     int E, NI, edge_major;
+    int box;                        // every vertex of the launch is a canonical axis-aligned box (canonical_box.h): BOX instantiation
     void *zedge, *mu, *copy;
     double *xv, *zv, *yv;
     int *counters;

@@ -11,11 +11,15 @@
 
 #ifdef GCS_WG_REVERSE
 #define EMU_FN wg_emu_vertex_step_rev
+#define EMU_BOX wg_emu_set_box_rev
 #define EMU_LDS wg_emu_lds_doubles_rev
 #else
 #define EMU_FN wg_emu_vertex_step
+#define EMU_BOX wg_emu_set_box
 #define EMU_LDS wg_emu_lds_doubles
 #endif
+
+static bool g_emu_box = false;      // set per call: run the BOX instantiation (the caller vouches for canonical boxes)
 
 template <int N>
 static void run_all(const gcs_wg::WgArgs<double> &a, double rho, double mu_scale, int lds, int *status, int *iters)
@@ -24,13 +28,16 @@ static void run_all(const gcs_wg::WgArgs<double> &a, double rho, double mu_scale
     for (int w = 0; w < a.n_vtx; ++w) {
         std::fill(smem.begin(), smem.end(), 0.0 / 0.0);
         int st = -9, it = 0;
-        gcs_wg::wg_solve_vertex<N, double>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
+        if (g_emu_box) gcs_wg::wg_solve_vertex<N, double, true>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
+        else gcs_wg::wg_solve_vertex<N, double, false>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
         status[a.vtx[w]] = st; iters[a.vtx[w]] = it;
         a.counters[0] += st != 0; a.counters[1] += it;
     }
 }
 
 extern "C" int EMU_LDS(int n, int U, int m) { return gcs_wg::wg_lds_doubles_n(n, U, m); }
+// 1: the following steps run the BOX instantiation of the program (every polytope must be a canonical box: canonical_box.h)
+extern "C" void EMU_BOX(int on) { g_emu_box = on != 0; }
 
 // one vertex step over the generic vertices of a graph; special vertices (s, t, no-flow) are left untouched
 extern "C" int EMU_FN(int n, int V, int E, int NI, const int *inc_ptr, const int *inc_edge, const int *inc_out,

@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "gcs_admm_amd", "csrc")
 @pytest.fixture(scope="module")
 def libs():
     src = os.path.join(HERE, "hostemu", "wg_emu.cpp")
-    deps = [src, os.path.join(CSRC, "vertex_wg.h"), os.path.join(CSRC, "gcs_math.h")]
+    deps = [src, os.path.join(CSRC, "vertex_wg.h"), os.path.join(CSRC, "gcs_math.h")]      # (rebuilt when the program changes)
     out = []
     for name, flags in (("libwgemu.so", []), ("libwgemu_rev.so", ["-DGCS_WG_REVERSE"])):
         so = os.path.join(HERE, "hostemu", name)
@@ -77,6 +77,36 @@ def test_workgroup_program_matches_oracle_and_is_order_independent(libs, oracle_
         o.edge_step(1.0)
     diffs = np.array(diffs)
     assert diffs.max() <= tol and np.median(diffs) <= max(1e-5, tol * 1e-2)
+
+
+@pytest.mark.parametrize("lat", [(5, 4, 2), (4, 3, 3), (4, 3, 6)])
+def test_box_instantiation_equals_generic(libs, oracle_lib, lat):
+    """the BOX instantiation of the workgroup program (canonical axis-aligned boxes: one-term facet rows, diagonal K_h and X_e)
+    against the generic one on the same lattice: the terms it drops are exact zeros, so the two agree to rounding; task-order
+    independence of the BOX regions (ascending / descending)"""
+    fwd, rev = libs
+    g = lattice_boxes(lat[0], lat[1], n=lat[2], seed=1)
+    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    for it in range(5):
+        z0, m0 = o.zedge.copy(), o.mu.copy()
+        a = wg_step(fwd, "wg_emu_vertex_step", g, z0, m0)
+        fwd.wg_emu_set_box(1); rev.wg_emu_set_box_rev(1)
+        try:
+            b = wg_step(fwd, "wg_emu_vertex_step", g, z0, m0)
+            c = wg_step(rev, "wg_emu_vertex_step_rev", g, z0, m0)
+        finally:
+            fwd.wg_emu_set_box(0); rev.wg_emu_set_box_rev(0)
+        gen = a[5]
+        assert b[4][0] == 0 and (b[6][gen] == 0).all() and np.array_equal(a[7], b[7])       # same Newton iteration counts
+        mask = np.zeros(2 * g.num_edges, bool)
+        for v in np.nonzero(gen)[0]:
+            mask[g.inc_ptr[v]:g.inc_ptr[v + 1]] = True
+        assert np.isfinite(b[0][:, mask]).all()
+        assert np.abs(a[0][:, mask] - b[0][:, mask]).max() <= 1e-9 and np.abs(a[3][gen] - b[3][gen]).max() <= 1e-9
+        assert np.abs(b[0][:, mask] - c[0][:, mask]).max() <= 1e-9
+        assert o.vertex_step(1.0, 1.0) == 0
+        assert np.abs(b[0][:, mask] - o.copy[:, mask]).max() <= 1e-6
+        o.edge_step(1.0)
 
 
 def test_inner_failure_keeps_previous_outputs(libs):
