@@ -496,6 +496,9 @@ template <int DIM> GCS_HD void wg_inverse_big(double *Lm, const double *piv, dou
 //   in : Mq  lower triangle of A (row-major, ld = DIM);   out: strictly lower part of Mq = L, rd[k] = 1 / D_k
 // (the diagonal and the upper triangle of Mq are left undefined).  Pivot rule of oracle chol(): a pivot that has
 // cancelled below CHOL_SKIP of its ORIGINAL diagonal entry is clamped there.
+// (Sending the pivot column through LDS -- one write, broadcast ds_read_b128 back -- instead of two readlanes per entry was
+// measured SLOWER at 25 x 25: 82 800 against 79 200 ticks per Newton iteration; the wait on the LDS round trip per column costs
+// more than the readlanes it saves.)
 // Host build: the same column-by-column elimination written serially.
 // ---------------------------------------------------------------------------------------------------------------
 template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)

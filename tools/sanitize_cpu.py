@@ -24,6 +24,26 @@ for name,g,fn in graphs:
         step(fn,g,o.zedge.copy(),o.mu.copy()); o.vertex_step(1.0,1.0,1); o.edge_step(1.0)
     print(name,'ok')
 
+# ---- the workgroup program's host build under the sanitizers
+wg = C.CDLL('/tmp/libwgemu_asan.so')
+def wg_step(g, z, m):
+    c = g.c; NI = 2 * g.num_edges; V = g.num_vertices
+    copy = np.zeros((c, NI)); xv = np.zeros((V, 2 * g.n)); zv = np.zeros_like(xv); yv = np.zeros(V)
+    cnt = np.zeros(2, dtype=np.int32); gen = np.zeros(V, dtype=np.int32); st = np.zeros(V, dtype=np.int32); it = np.zeros(V, dtype=np.int32)
+    r = wg.wg_emu_vertex_step(g.n, V, g.num_edges, NI, p(g.inc_ptr), p(g.inc_edge), p(g.inc_out), p(g.poly_ptr), p(g.poly_A), p(g.poly_b),
+                              p(g.interior), g.src, g.dst, p(z), p(m), C.c_double(1.0), C.c_double(1.0), C.c_double(1e-4), C.c_double(1e-9), 60,
+                              p(copy), p(xv), p(zv), p(yv), p(cnt), p(gen), p(st), p(it))
+    assert r == 0 and cnt[0] == 0
+wg_graphs = [('benchmark4', load_fixture('benchmark4')[1], 0), ('lattice n2', lattice_boxes(6, 5, seed=1), 0), ('lattice n3 box', lattice_boxes(4, 3, n=3, seed=1), 1),
+             ('lattice n6', lattice_boxes(4, 3, n=6, seed=1), 0), ('lattice n6 box', lattice_boxes(4, 3, n=6, seed=1), 1), ('star', graph_from_sets(*star_case(24)), 0)]
+for name, g, box in wg_graphs:
+    o = Oracle(g, ipm_tol=1e-9)
+    wg.wg_emu_set_box(box)
+    for it in range(4):
+        wg_step(g, o.zedge.copy(), o.mu.copy()); o.vertex_step(1.0, 1.0, 1); o.edge_step(1.0)
+    wg.wg_emu_set_box(0)
+    print('workgroup program,', name, 'ok')
+
 # ---- oracle under the sanitizers
 import oracle.oracle as O
 O._lib=C.CDLL('/tmp/libo_asan.so'); O._lib.oracle_compute_cost.restype=C.c_double
