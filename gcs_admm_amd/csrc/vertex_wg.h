@@ -805,10 +805,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             if (q < NX) {
                 r = -REG_DELTA * sm[W::XV + q] - sm[W::XBG + q] - sm[W::XBG + NX + q];
                 if (prox) r -= sm[W::PQ + q] * (sm[W::XV + q] + CEN[q < N ? q : q - N] - sm[W::PC + q]);
-                if (wk) {
-#pragma unroll 4
-                    for (int u = 0; u <= d; ++u) r -= UN(u)[W::GX + q];
-                }
+                if (wk) r -= sm[W::SOL + q];       // sum over the units of G'kappa's x part (solve_head's first region put it there)
                 for (int s = 0; s < 2; ++s) {
                     const double *BXs = sm + W::BXS + s * NW * NX;
 #pragma unroll
@@ -825,7 +822,18 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
     };
     auto solve_head = [&](bool wk) {
-        { Place pl; te_tasks(pl, wk); }
+        {
+            Place pl;
+            te_tasks(pl, wk);
+            if (wk) {      // rides here: the x part of G'kappa summed over the units, for the right-hand side (SOL is free until the solve)
+                WG_FOR_AT(q, NX, pl.at(NX)) {
+                    double acc = 0;
+#pragma unroll 4
+                    for (int u = 0; u <= d; ++u) acc += UN(u)[W::GX + q];
+                    sm[W::SOL + q] = acc;
+                }
+            }
+        }
         WG_SYNC();
         WG_STAMP(30);
         { Place pl; bg_tasks(pl); }
