@@ -155,7 +155,9 @@ def main():
     out = {"metric": "admm_iterations_per_sec", "value": its, "unit": "iterations/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
            "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": its / REF_PUBLISHED_ITS if (args.workload == "benchmark4" and world == 1) else None,
+           # the reference publishes no throughput number for this metric (`published` is {}); the rate derived from its
+           # result record (solver time only, unknown hardware) is reported under reference_published, not as a baseline ratio
+           "vs_baseline": None,
            "dtype": "f64" if dtype == "f64" else "f64 (interior point) on f32 state",
            "data": "synthetic" if args.workload != "benchmark4" else "fixture of the reference's test_data/benchmark4.py",
            "config": {"workload": args.workload, "V": g.num_vertices, "E": g.num_edges, "n": g.n,
@@ -230,7 +232,9 @@ def main():
             out["iters_to_eps"] = {"eps_abs": 1e-6, "eps_rel": 1e-6, "iterations": tight["iterations"], "status": tight["status"],
                                    "cost": tight["cost"], "rel_gap_to_classic": abs(tight["cost"] - classic) / classic,
                                    "wall_time_s": tight["wall_time_s"]}
-            out["reference_published"] = {"its_per_sec": REF_PUBLISHED_ITS, "note": "465 it / 37.88 s solver-time-only, hardware unknown (BASELINE.md)"}
+            out["reference_published"] = {"its_per_sec": REF_PUBLISHED_ITS, "ratio_of_this_run": its / REF_PUBLISHED_ITS,
+                                          "note": "derived from the reference's committed record: 465 it / 37.88 s solver-time-only, hardware unknown "
+                                                  "(BASELINE.md section 1: not a published throughput number, hence vs_baseline = null)"}
         # ---- CPU baseline: the oracle on the host cores, bounded sample ----
         if not args.no_cpu and not args.loop_only and world == 1:
             out["cpu_baseline"] = cpu_baseline(g, args.workload)
