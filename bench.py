@@ -235,6 +235,13 @@ def main():
             out["reference_published"] = {"its_per_sec": REF_PUBLISHED_ITS, "ratio_of_this_run": its / REF_PUBLISHED_ITS,
                                           "note": "derived from the reference's committed record: 465 it / 37.88 s solver-time-only, hardware unknown "
                                                   "(BASELINE.md section 1: not a published throughput number, hence vs_baseline = null)"}
+        if args.workload == "s10k" and not args.loop_only:
+            # BASELINE config 3's second half: the reference's own stop rule (defaults) on the f32 state
+            res = dev.solve(timed=True)
+            out["convergence"] = {"iterations_to_stop": res["iterations"], "status": res["status"], "cost": res["cost"],
+                                  "solve_time_s": res["device_time_s"], "loop_wall_time_s": res["wall_time_s"],
+                                  "iterations_per_sec_to_stop": res["iterations"] / max(res["wall_time_s"], 1e-12),
+                                  "note": "f32 state; the f64 state and the CPU oracle stop at the same iteration (tests/test_gpu_configs.py)"}
         # ---- CPU baseline: the oracle on the host cores, bounded sample ----
         if not args.no_cpu and not args.loop_only and world == 1:
             out["cpu_baseline"] = cpu_baseline(g, args.workload)
