@@ -62,14 +62,16 @@ def cpu_baseline(g, workload, seconds=20.0):
     from oracle.oracle import Oracle
     ncpu = os.cpu_count() or 1
     n_probe = 20 if workload == "benchmark4" else 2
-    best, cores = 0.0, 1
+    best, cores, single = 0.0, 1, None
     for th in sorted({1, 8, 16, 32, 64, 128, ncpu}):
-        if th > ncpu or (th == 1 and g.num_vertices > 5000 and ncpu > 1):
+        if th > ncpu or (th == 1 and g.num_vertices > 20000 and ncpu > 1):
             continue
         o = Oracle(g, ipm_tol=1e-9)
         t0 = time.perf_counter()
         o.run(max_it=n_probe, eps_abs=0.0, eps_rel=0.0, nthreads=th)
         r = n_probe / (time.perf_counter() - t0)
+        if th == 1:
+            single = r          # a one-thread run beside the all-cores run
         if r > best:
             best, cores = r, th
     n_it = max(n_probe, int(min(seconds * best, 2000)))
@@ -78,6 +80,7 @@ def cpu_baseline(g, workload, seconds=20.0):
     o.run(max_it=n_it, eps_abs=0.0, eps_rel=0.0, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": n_it / dt, "unit": "iterations/s", "cores": cores, "kind": "port", "host_cpus": ncpu,
+            "single_thread_value": single, "single_thread_sample": None if single is None else f"{n_probe} iterations, 1 thread",
             "sample": f"{n_it} iterations of the same workload from the zero state (oracle/gcs_oracle.c, OpenMP over vertices, "
                       f"best thread count of a sweep up to {ncpu})"}
 
