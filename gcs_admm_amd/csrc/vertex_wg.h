@@ -64,6 +64,8 @@ __device__ __forceinline__ int wg_tid()
 #define WG_CONE() if (gcs_wg::wg_tid() == gcs_wg::WG_THREADS - 1)
 // work that one WAVEFRONT does with a matrix row per lane (wave_ldl below): no barrier inside, broadcasts by readlane
 #define WG_WAVE0() if (gcs_wg::wg_tid() < 64)
+// the same for the first `cnt` wavefronts, each with its own index w (one matrix per wavefront)
+#define WG_FIRST_WAVES(w, cnt) if (const int w = gcs_wg::wg_tid() >> 6; w < (cnt))
 // WAVE-LOCAL PIPELINE.  Tasks (q, i): `count` items (units) are dealt round-robin to the first WG_ITEM_WAVES wavefronts (item q
 // belongs to wavefront q % WG_ITEM_WAVES; the last wavefront is left to the serial cone thread), i runs over the PER sub-tasks of
 // an item, shared by the lanes of the owning wavefront.  Successive WG_ITEM_FOR loops over the SAME items exchange data through
@@ -94,6 +96,7 @@ __device__ __forceinline__ int wg_tid()
 #define WG_ONE() if (true)
 #define WG_CONE() if (true)
 #define WG_WAVE0() if (true)
+#define WG_FIRST_WAVES(w, cnt) for (int w = 0; w < (cnt); ++w)
 #define WG_ITEM_FOR(q, i, count, PER) WG_FOR(t_, (count) * (PER)) if (const int q = t_ / (PER), i = t_ - q * (PER); true)
 #define WG_REPL_FOR(i, cnt) WG_FOR(i, cnt)
 #define WG_WAVE_SYNC() do { } while (0)
@@ -264,226 +267,7 @@ GCS_HD void tri_decode(int t, int &r, int &c)
 // ranges used here: dividend < 2^20, divisor <= 1024; the margin (0.5/div) dwarfs the float rounding)
 GCS_HD int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Cholesky of `count` SPD matrices of dimension DIM in LDS (row-major, ld = DIM, stride `mstride` between matrices):
-// lower triangle in place (strictly lower part = L, diagonal untouched), inverse pivots in piv (stride `pstride`).
-// Pivot rule of oracle chol(): a pivot that has cancelled below CHOL_SKIP of its ORIGINAL diagonal entry is clamped there.
-//
-// Tile-blocked, right-looking: the matrix is cut into tiles of at most 9 columns (5, 7, 9 -> one tile; 13 -> 6 + 7;
-// 25 -> 8 + 8 + 9).  Per tile: (1) ONE thread per matrix factors the diagonal tile in registers (packed lower, all
-// indices compile-time: ~TS^3/6 dependent FMAs, no LDS traffic inside); (2) one thread per row below solves its TS
-// entries against the tile (registers); (3) one thread per entry of the trailing matrix subtracts the tile's outer
-// product.  A column-at-a-time cooperative factorisation costs one barrier and ~1000 issue cycles PER COLUMN at these
-// sizes (measured, profiles/r02): the tiles keep the dependent chain in registers and need three barriers per tile.
-// ---------------------------------------------------------------------------------------------------------------
 GCS_HD constexpr int pki(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, i >= j
-
-template <int DIM, int T0, int TS>
-GCS_HD void wg_chol_tile(double *mats, double *piv, int count, int mstride, int pstride)
-{
-    constexpr int REST = DIM - T0 - TS;
-    WG_FOR(q, count) {
-        double *Mq = mats + (size_t)q * mstride, *pq = piv + (size_t)q * pstride;
-        double a[TS * (TS + 1) / 2], od[TS];
-#pragma unroll
-        for (int i = 0; i < TS; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) a[pki(i, j)] = Mq[(T0 + i) * DIM + T0 + j];
-        if constexpr (T0 == 0) {
-            // original diagonal: of this tile from the registers; of the later tiles saved now, before the trailing
-            // updates change it
-#pragma unroll
-            for (int j = 0; j < TS; ++j) od[j] = a[pki(j, j)];
-#pragma unroll
-            for (int j = TS; j < DIM; ++j) pq[j] = Mq[j * DIM + j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < TS; ++j) od[j] = pq[T0 + j];
-        }
-#pragma unroll
-        for (int j = 0; j < TS; ++j) {
-            double dj = a[pki(j, j)];
-#pragma unroll
-            for (int k = 0; k < j; ++k) dj -= a[pki(j, k)] * a[pki(j, k)];
-            if (!(dj > CHOL_SKIP * od[j])) dj = od[j] > 0.0 ? CHOL_SKIP * od[j] : 1.0;
-            const double inv = rsqrt_nr(dj);
-            pq[T0 + j] = inv;
-#pragma unroll
-            for (int i = j + 1; i < TS; ++i) {
-                double sij = a[pki(i, j)];
-#pragma unroll
-                for (int k = 0; k < j; ++k) sij -= a[pki(i, k)] * a[pki(j, k)];
-                a[pki(i, j)] = sij * inv;
-            }
-        }
-#pragma unroll
-        for (int i = 1; i < TS; ++i)
-#pragma unroll
-            for (int j = 0; j < i; ++j) Mq[(T0 + i) * DIM + T0 + j] = a[pki(i, j)];
-    }
-    WG_SYNC();
-    if constexpr (REST > 0) {
-        WG_FOR(t, count * REST) {      // rows below the tile: L[i][tile] = A[i][tile] L_tile^{-T}
-            const int q = t / REST, i = T0 + TS + (t - q * REST);
-            double *Mq = mats + (size_t)q * mstride;
-            const double *pq = piv + (size_t)q * pstride;
-            double x[TS];
-#pragma unroll
-            for (int k = 0; k < TS; ++k) x[k] = Mq[i * DIM + T0 + k];
-#pragma unroll
-            for (int k = 0; k < TS; ++k) {
-                double sk = x[k];
-#pragma unroll
-                for (int pp = 0; pp < k; ++pp) sk -= x[pp] * Mq[(T0 + k) * DIM + T0 + pp];
-                x[k] = sk * pq[T0 + k];
-            }
-#pragma unroll
-            for (int k = 0; k < TS; ++k) Mq[i * DIM + T0 + k] = x[k];
-        }
-        WG_SYNC();
-        WG_FOR(t, count * REST * REST) {   // trailing matrix (lower triangle): A[i][j] -= L[i][tile] . L[j][tile]
-            const int q = t / (REST * REST), rr = t - q * (REST * REST), ri = rr / REST, rj = rr - ri * REST;
-            if (ri < rj) continue;
-            double *Mq = mats + (size_t)q * mstride;
-            const int i = T0 + TS + ri, j = T0 + TS + rj;
-            double acc = 0;
-#pragma unroll
-            for (int k = 0; k < TS; ++k) acc += Mq[i * DIM + T0 + k] * Mq[j * DIM + T0 + k];
-            Mq[i * DIM + j] -= acc;
-        }
-        WG_SYNC();
-    }
-}
-
-template <int DIM> GCS_HD void wg_chol(double *mats, double *piv, int count, int mstride, int pstride)
-{
-    constexpr int NT = (DIM + 8) / 9, B1 = DIM / NT, B2 = 2 * DIM / NT;
-    static_assert(NT <= 3, "tile plan covers dimensions up to 27");
-    if constexpr (NT == 1) wg_chol_tile<DIM, 0, DIM>(mats, piv, count, mstride, pstride);
-    else if constexpr (NT == 2) {
-        wg_chol_tile<DIM, 0, B1>(mats, piv, count, mstride, pstride);
-        wg_chol_tile<DIM, B1, DIM - B1>(mats, piv, count, mstride, pstride);
-    } else {
-        wg_chol_tile<DIM, 0, B1>(mats, piv, count, mstride, pstride);
-        wg_chol_tile<DIM, B1, B2 - B1>(mats, piv, count, mstride, pstride);
-        wg_chol_tile<DIM, B2, DIM - B2>(mats, piv, count, mstride, pstride);
-    }
-}
-
-// column c of the inverse of the SPD matrix whose factor is (Lm strictly lower, piv inverse pivots): out[i*ldo + c]
-// (WG_FENCE: a compiler-level fence per row on the device; without it the scheduler hoists every LDS load of the
-//  factor to the top of the unrolled solve and the live ranges spill)
-template <int DIM> GCS_HD void chol_inverse_col(const double *Lm, const double *piv, int c, double *out, int ldo)
-{
-    double x[DIM];
-    // up to 9 x 9 the whole factor is read in one batch (45 values: one LDS round trip); larger ones row by row
-#pragma unroll
-    for (int i = 0; i < DIM; ++i) {
-        double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= Lm[i * DIM + k] * x[k];
-        x[i] = s * piv[i];
-        if constexpr (DIM > 9) WG_FENCE();
-    }
-#pragma unroll
-    for (int i = DIM - 1; i >= 0; --i) {
-        double s = x[i];
-#pragma unroll
-        for (int k = i + 1; k < DIM; ++k) s -= Lm[k * DIM + i] * x[k];
-        x[i] = s * piv[i];
-        if constexpr (DIM > 9) WG_FENCE();
-    }
-#pragma unroll
-    for (int i = 0; i < DIM; ++i) out[i * ldo + c] = x[i];
-}
-
-// Inverse of a larger SPD matrix (three tiles, e.g. 25 = 8 + 8 + 9) from its tiled factor, every step a parallel region:
-//   L^{-1} = [X11 0 0; X21 X22 0; X31 X32 X33],  Xii = Lii^{-1},  X21 = -X22 (L21 X11),  X32 = -X33 (L32 X22),
-//   X31 = -X33 (L31 X11 + L32 X21);  then A^{-1} = L^{-T} L^{-1} entry by entry.
-// `Lm` holds the factor (strictly lower part, inverse pivots in piv) and receives A^{-1} (full, symmetric); `linv` is a
-// DIM x DIM scratch.  The column-at-a-time solves of chol_inverse_col cost a dependent chain of 2 DIM rows per column.
-template <int DIM> GCS_HD void wg_inverse_big(double *Lm, const double *piv, double *linv)
-{
-    constexpr int NT = (DIM + 8) / 9, B1 = DIM / NT, B2 = 2 * DIM / NT;
-    static_assert(NT == 3, "three-tile plan");
-    constexpr int S0 = B1, S1 = B2 - B1, S2 = DIM - B2;
-    // (1) inverses of the three diagonal tiles, one thread per (tile, column), the column in registers; the rest of linv := 0
-    WG_FOR(c, DIM) {
-        const int t0 = c < B1 ? 0 : (c < B2 ? B1 : B2), ts = c < B1 ? S0 : (c < B2 ? S1 : S2), cl = c - t0;
-        double x[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            double sx = (i == cl) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) sx -= (i < ts ? Lm[(t0 + i) * DIM + t0 + k] : 0.0) * x[k];
-            x[i] = i < ts ? sx * piv[t0 + i] : 0.0;
-        }
-        for (int i = 0; i < DIM; ++i)
-            if (i < t0 || i >= t0 + ts) linv[i * DIM + c] = 0.0;
-#pragma unroll
-        for (int il = 0; il < 9; ++il)
-            if (il < ts) linv[(t0 + il) * DIM + c] = x[il];
-    }
-    WG_SYNC();
-    // (2) T21 = L21 X11, T32 = L32 X22, T31a = L31 X11 (into linv's off-diagonal blocks)
-    WG_FOR(t, S1 * S0 + S2 * S1 + S2 * S0) {
-        int i, j, k0, kn;
-        if (t < S1 * S0) { i = B1 + t / S0; j = t % S0; k0 = 0; kn = S0; }
-        else if (t < S1 * S0 + S2 * S1) { const int q = t - S1 * S0; i = B2 + q / S1; j = B1 + q % S1; k0 = B1; kn = S1; }
-        else { const int q = t - S1 * S0 - S2 * S1; i = B2 + q / S0; j = q % S0; k0 = 0; kn = S0; }
-        double acc = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc += k < kn ? Lm[i * DIM + k0 + k] * linv[(k0 + k) * DIM + j] : 0.0;
-        linv[i * DIM + j] = acc;
-    }
-    WG_SYNC();
-    // (3) X21 = -X22 T21 (into Lm's 21 block: L21 is dead)
-    WG_FOR(t, S1 * S0) {
-        const int i = B1 + t / S0, j = t % S0;
-        double acc = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc -= k < S1 ? linv[i * DIM + B1 + k] * linv[(B1 + k) * DIM + j] : 0.0;
-        Lm[i * DIM + j] = acc;
-    }
-    WG_SYNC();
-    // (4) T31 = T31a + L32 X21
-    WG_FOR(t, S2 * S0) {
-        const int i = B2 + t / S0, j = t % S0;
-        double acc = linv[i * DIM + j];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc += k < S1 ? Lm[i * DIM + B1 + k] * Lm[(B1 + k) * DIM + j] : 0.0;
-        linv[i * DIM + j] = acc;
-    }
-    WG_SYNC();
-    // (5) X32 = -X33 T32, X31 = -X33 T31 (into Lm's 32 and 31 blocks)
-    WG_FOR(t, S2 * (S1 + S0)) {
-        const int i = B2 + t / (S1 + S0), jj = t % (S1 + S0), j = jj < S1 ? B1 + jj : jj - S1;
-        double acc = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc -= k < S2 ? linv[i * DIM + B2 + k] * linv[(B2 + k) * DIM + j] : 0.0;
-        Lm[i * DIM + j] = acc;
-    }
-    WG_SYNC();
-    // (6) gather L^{-1} in linv (its off-diagonal blocks sit in Lm)
-    WG_FOR(t, S1 * S0 + S2 * (S1 + S0)) {
-        int i, j;
-        if (t < S1 * S0) { i = B1 + t / S0; j = t % S0; }
-        else { const int q = t - S1 * S0; i = B2 + q / (S1 + S0); j = q % (S1 + S0); j = j < S1 ? B1 + j : j - S1; }
-        linv[i * DIM + j] = Lm[i * DIM + j];
-    }
-    WG_SYNC();
-    // (7) A^{-1}[i][j] = sum_k Linv[k][i] Linv[k][j] (rows k < max(i, j) of L^{-1} hold zeros)
-    WG_FOR(t, DIM * (DIM + 1) / 2) {
-        int i, j;
-        tri_decode(t, i, j);
-        double acc = 0;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) acc += linv[k * DIM + i] * linv[k * DIM + j];
-        Lm[i * DIM + j] = acc;
-        Lm[j * DIM + i] = acc;
-    }
-    WG_SYNC();
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The reduced border system inside ONE wavefront.  A = L D L' (L unit lower) of one SPD matrix of dimension DIM <= 64
@@ -505,7 +289,7 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
 {
     static_assert(DIM <= 64, "one row per lane");
 #if WG_DEVICE
-    const int lane = wg_tid(), row = lane < DIM ? lane : DIM - 1;      // spare lanes shadow the last row and store nothing
+    const int lane = wg_tid() & 63, row = lane < DIM ? lane : DIM - 1;      // spare lanes shadow the last row and store nothing
     double a[DIM];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) a[j] = Mq[row * DIM + j];
@@ -514,7 +298,7 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
         double dk = lane_bcast(a[k], k);
-        const double odk = lane_bcast(od, k);
+        const double odk = lane_bcast(od, k);     // original diagonal entry (an LDS read here would sit on the pivot-to-pivot chain)
         if (!(dk > CHOL_SKIP * odk)) dk = odk > 0.0 ? CHOL_SKIP * odk : 1.0;
         const double rk = rcp(dk), col = a[k], l = col * rk;
         a[k] = l;
@@ -550,7 +334,7 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
 template <int DIM> GCS_HD void wave_ldl_solve(const double *Mq, const double *rd, const double *b, double *x)
 {
 #if WG_DEVICE
-    const int lane = wg_tid(), row = lane < DIM ? lane : DIM - 1;
+    const int lane = wg_tid() & 63, row = lane < DIM ? lane : DIM - 1;
     double l[DIM], v = b[row];
 #pragma unroll
     for (int k = 0; k < DIM - 1; ++k) l[k] = k < row ? Mq[row * DIM + k] : 0.0;
@@ -572,6 +356,39 @@ template <int DIM> GCS_HD void wave_ldl_solve(const double *Mq, const double *rd
         for (int i = 0; i < k; ++i) v[i] -= Mq[k * DIM + i] * v[k];
     for (int i = 0; i < DIM; ++i) x[i] = v[i];
 #endif
+}
+
+// column c of A^{-1} from the factor of wave_ldl (Lm: unit lower factor in the strictly lower part, rd: 1 / D): one thread per
+// column, the column in registers (the side systems need their inverse as a matrix: it enters the border system)
+// (WG_FENCE: a compiler-level fence per row on the device; without it the scheduler hoists every LDS load of the
+//  factor to the top of the unrolled solve and the live ranges spill.  The scaling by 1 / D sits INSIDE the backward sweep: as a
+//  loop of its own it cost the generic n = 6 kernel 90 registers and scratch; the stores stay a loop of their own: inside the
+//  sweep they made the n = 6 iteration 6 % slower.)
+// LOWREG: the stores inside the sweep as well (the generic n = 6 kernel, which otherwise spills)
+template <int DIM, bool LOWREG> GCS_HD void ldl_inverse_col(const double *Lm, const double *rd, int c, double *out, int ldo)
+{
+    double x[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+        double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= Lm[i * DIM + k] * x[k];
+        x[i] = s;
+        if constexpr (DIM > 9) WG_FENCE();
+    }
+#pragma unroll
+    for (int i = DIM - 1; i >= 0; --i) {
+        double s = x[i] * rd[i];
+#pragma unroll
+        for (int k = i + 1; k < DIM; ++k) s -= Lm[k * DIM + i] * x[k];
+        x[i] = s;
+        if constexpr (LOWREG) out[i * ldo + c] = s;
+        if constexpr (DIM > 9) WG_FENCE();
+    }
+    if constexpr (!LOWREG) {
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) out[i * ldo + c] = x[i];
+    }
 }
 
 // Nesterov-Todd scaling of the cone from (s, z): wb (unit hyperbolic vector), eta; false on a boundary point
@@ -1165,7 +982,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 un[W::RV + h] = ch;
                 continue;
             }
-            double a[NS], li[NS], kv[N], pv[N];
+            double a[NS], kv[N], pv[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 kv[i] = un[W::K + (h * N + i) * NW + 2 * N];
@@ -1189,8 +1006,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                     a[pki(i, j)] = sij * inv;
                 }
             }
-#pragma unroll
-            for (int c = 0; c < N; ++c)             // L^{-1}, lower
+            double (&li)[NS] = a;                  // L^{-1} (lower) IN PLACE of L: column c reads columns >= c of L only, and an entry
+#pragma unroll                                  // of column c is overwritten after its last use (21 doubles fewer at n = 6)
+            for (int c = 0; c < N; ++c)
 #pragma unroll
                 for (int i = c; i < N; ++i) {
                     double sx = (i == c) ? 1.0 : 0.0;
@@ -1310,11 +1128,14 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // ================= sides: factor, invert, Y_s = Bs^{-1} BXs (over the dead factor) =================
         Place ply;
         if (sides) {
-            wg_chol<NW>(sm + W::BS, sm + W::PIVS, 2, NW * NW, NW);
+            static_assert(WG_WAVES >= 2, "one wavefront per side");
+            // B_in and B_out = L D L' concurrently, one wavefront each, one matrix row per lane (one call site: one copy of the code)
+            WG_FIRST_WAVES(sd, 2) wave_ldl<NW>(sm + W::BS + sd * NW * NW, sm + W::PIVS + sd * NW);
+            WG_SYNC();
             WG_STAMP(7);
             WG_FOR(t, 2 * NW) {
                 const int s = t / NW, c = t - s * NW;
-                chol_inverse_col<NW>(sm + W::BS + s * NW * NW, sm + W::PIVS + s * NW, c, sm + W::BSI + s * NW * NW, NW);
+                ldl_inverse_col<NW, (!BOX && NW > 9)>(sm + W::BS + s * NW * NW, sm + W::PIVS + s * NW, c, sm + W::BSI + s * NW * NW, NW);
             }
             WG_SYNC();
             WG_FOR_AT(t, 2 * NW * NX, ply.at(2 * NW * NX)) {
