@@ -711,6 +711,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     std::vector<int> special_vtx, special_kind, wave_slot_ptr{0}, wave_vtx, wg_vtx;
     std::vector<char> on_wave(V, 0);
     int wg_lds = 0, MMw = 1;
+    int wg_lds_box = 0;       // LDS per workgroup under the BOX instantiation's layout (used when every vertex turns out to be a box)
     bool wg_all_box = g->wave_generic_rows == 0;      // (the knob that forces the generic wavefront variants forces this one too)
     bool all_m4 = (n == 2) && g->wave_generic_rows != 1, all_box = all_m4 && g->wave_generic_rows != 2;
     for (int v = 0; v < V; ++v) {
@@ -723,6 +724,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         } else if (n != 2 || d + 1 > WAVE || prefer_wg) {
             wg_vtx.push_back(v);
             wg_lds = std::max(wg_lds, gcsadmm_wg_lds_bytes(n, d + 1, m));
+            wg_lds_box = std::max(wg_lds_box, gcsadmm_wg_lds_bytes(n, d + 1, m, true));
             if (wg_all_box && !canonical_box(n, m, g->poly_A + (size_t)g->poly_ptr[v] * n)) wg_all_box = false;
         } else {
             on_wave[v] = 1;
@@ -731,6 +733,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
             if (all_m4 && all_box && !canonical_box(2, m, g->poly_A + (size_t)g->poly_ptr[v] * 2)) all_box = false;   // [+e0, +e1, -e0, -e1]
         }
     }
+    if (wg_all_box && n > 2 && !wg_vtx.empty()) wg_lds = wg_lds_box;      // the BOX instantiation (n > 2) and its structured unit layout
     if (wg_lds > 160 * 1024) return fail(GCSADMM_ERR_UNSUPPORTED, "a vertex sub-problem (degree x facets) does not fit the 160 KB of LDS of a CU");
     // heaviest sub-problems first: the launch ends when its slowest workgroup does
     std::stable_sort(wg_vtx.begin(), wg_vtx.end(), [&](int a, int b) {

@@ -20,6 +20,8 @@
 // exactly equivalent as long as the tasks of a region are independent (tests/hostemu/wg_emu.cpp runs them in
 // ascending and in descending order and compares).
 #pragma once
+#include <type_traits>
+
 #include "gcs_math.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -176,10 +178,31 @@ template <int N> struct WL {
     static GCS_HD int unit_stride(int m) { return (ROWS + 12 * m) | 1; }
     static GCS_HD int total(int U, int m) { return FIXED + pad2(U * unit_stride(m)) + pad2(m * N) + pad2(m); }
 };
-template <int N> GCS_HD int wg_lds_doubles(int U, int m) { return WL<N>::total(U, m); }
-inline int wg_lds_doubles_n(int n, int U, int m)
+// The same for the BOX instantiation (canonical axis-aligned boxes, wg_solve_vertex<N, T, true>): the fixed block is WL<N>'s; a unit
+// holds K_e, X_e and B_e = K_e^{-1} in their STRUCTURED forms instead of three dense matrices (86 instead of 496 doubles at n = 6):
+//   K_e = diag(KD) + the y column KY (both ways) + KYY,     X_e = diag(XD) on the x part + the y row XY,
+//   B_e = diag(BD) + BRS * BW BW'   (BW = (w_1, w_2, -1): the closed form of the block inverse),   B_e X_e = diag(BD XD) + BRS * BW BQ'.
+// That is what lets a CU hold three workgroups of BASELINE config 5 (47 KB each) instead of two (77 KB).
+// (No K, X, B members: a generic access in a BOX path does not compile.)
+template <int N> struct WLBox {
+    using G = WL<N>;
+    using D = WD<N>;
+    static constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1;
+    static constexpr int CEN = G::CEN, XV = G::XV, DX = G::DX, NU = G::NU, DNU = G::DNU, BS = G::BS, BSI = G::BSI, BXS = G::BXS, PIVS = G::PIVS,
+                         BG = G::BG, XBG = G::XBG, XBX = G::XBX, XS = G::XS, RP = G::RP, VV = G::VV, WW = G::WW, M = G::M, PIVM = G::PIVM,
+                         RHS = G::RHS, SOL = G::SOL, SOC = G::SOC, PQ = G::PQ, PC = G::PC, SC = G::SC, RED = G::RED, FIXED = G::FIXED;
+    static constexpr int P = G::P, DW = G::DW, TG = G::TG, TF = G::TF, LB = G::LB, KB = G::KB, DLB = G::DLB, G0 = G::G0, GU = G::GU, GX = G::GX,
+                         TE = G::TE, RV = G::RV;
+    static constexpr int KD = G::K, KY = KD + pad2(NX), KYY = KY + pad2(NX), XD = KYY + 2, XY = XD + pad2(NX),
+                         BD = XY + pad2(NX), BW = BD + pad2(NX), BRS = BW + pad2(NW), BQ = BRS + 2, ROWS = BQ + pad2(NX);
+    static GCS_HD int unit_stride(int m) { return (ROWS + 12 * m) | 1; }
+    static GCS_HD int total(int U, int m) { return FIXED + pad2(U * unit_stride(m)) + pad2(m * N) + pad2(m); }
+};
+template <int N> GCS_HD int wg_lds_doubles(int U, int m, bool box = false) { return box ? WLBox<N>::total(U, m) : WL<N>::total(U, m); }
+// (the BOX layout exists where the BOX instantiation does: n > 2)
+inline int wg_lds_doubles_n(int n, int U, int m, bool box = false)
 {
-    return n == 2 ? wg_lds_doubles<2>(U, m) : (n == 3 ? wg_lds_doubles<3>(U, m) : wg_lds_doubles<6>(U, m));
+    return n == 2 ? wg_lds_doubles<2>(U, m) : (n == 3 ? wg_lds_doubles<3>(U, m, box) : wg_lds_doubles<6>(U, m, box));
 }
 
 template <class T> struct WgArgs {
@@ -453,7 +476,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 {
     using D = WD<N>;
     using SO = WSoc<N>;
-    using W = WL<N>;
+    using W = std::conditional_t<BOX, WLBox<N>, WL<N>>;       // LDS layout: dense K_e / X_e / B_e per unit, or their structured forms
     constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1, Q = D::Q, NS = D::NS, TA = D::TA;
     const bool prox = a.prox_q != nullptr;       // border-only problem with a separable quadratic (no blocks, no sides)
     const int lo = a.inc_ptr[v], d = prox ? 0 : a.inc_ptr[v + 1] - lo, d_in = prox ? 0 : a.deg_in[v], d_out = d - d_in;
@@ -574,8 +597,16 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const int u = 1 + t / NW, i = t - (u - 1) * NW;
             double *un = UN(u);
             double s = 0;
+            if constexpr (BOX) {       // B (-g) with B = diag(BD) + BRS BW BW'
+                double wg = 0;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) s -= un[W::B + i * NW + k] * gval(un, u, k, wk);
+                for (int k = 0; k < NW; ++k) wg += un[W::BW + k] * gval(un, u, k, wk);
+                s = -(un[W::BRS] * un[W::BW + i]) * wg;
+                if (i < 2 * N) s -= un[W::BD + i] * gval(un, u, i, wk);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) s -= un[W::B + i * NW + k] * gval(un, u, k, wk);
+            }
             un[W::TE + i] = s;
         }
     };
@@ -594,12 +625,12 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll 2
             for (int u = ulo; u <= uhi; ++u) {
                 const double *un = UN(u);
-                if constexpr (BOX) acc += un[W::X + c * NX + c] * un[W::TE + c];
+                if constexpr (BOX) acc += un[W::XD + c] * un[W::TE + c] + un[W::XY + c] * un[W::TE + 2 * N];
                 else {
 #pragma unroll
                     for (int k = 0; k < N; ++k) acc += un[W::X + (h * N + k) * NX + c] * un[W::TE + h * N + k];
+                    acc += un[W::X + 2 * N * NX + c] * un[W::TE + 2 * N];
                 }
-                acc += un[W::X + 2 * N * NX + c] * un[W::TE + 2 * N];
             }
             sm[W::XBG + t] = acc;
         }
@@ -734,13 +765,16 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const int u = 1 + q;
             double *un = UN(u);
             double acc = -gval(un, u, i, wk) + sm[W::DNU + side_of(u) * NW + i];
-            if (i < 2 * N) {
-                if constexpr (BOX) acc -= un[W::X + i * NX + i] * sm[W::DX + i];
+            if constexpr (BOX) {
+                if (i < 2 * N) acc -= un[W::XD + i] * sm[W::DX + i];
                 else {
-                    const int h = i / N;
 #pragma unroll
-                    for (int k = 0; k < N; ++k) acc -= un[W::X + i * NX + h * N + k] * sm[W::DX + h * N + k];
+                    for (int c = 0; c < NX; ++c) acc -= un[W::XY + c] * sm[W::DX + c];
                 }
+            } else if (i < 2 * N) {
+                const int h = i / N;
+#pragma unroll
+                for (int k = 0; k < N; ++k) acc -= un[W::X + i * NX + h * N + k] * sm[W::DX + h * N + k];
             } else {
 #pragma unroll
                 for (int c = 0; c < NX; ++c) acc -= un[W::X + i * NX + c] * sm[W::DX + c];
@@ -751,8 +785,16 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_ITEM_FOR(q, i, d, NW) {      // d w_e = B_e r_e
             double *un = UN(1 + q);
             double acc = 0;
+            if constexpr (BOX) {
+                double wr = 0;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) acc += un[W::B + i * NW + k] * un[W::RV + k];
+                for (int k = 0; k < NW; ++k) wr += un[W::BW + k] * un[W::RV + k];
+                acc = (un[W::BRS] * un[W::BW + i]) * wr;
+                if (i < 2 * N) acc += un[W::BD + i] * un[W::RV + i];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) acc += un[W::B + i * NW + k] * un[W::RV + k];
+            }
             un[W::DW + i] = acc;
         }
         WG_SYNC();
@@ -877,59 +919,69 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // back to back: with the K_yy tasks right behind the K entries the second wavefront was this region's critical path,
         // 3 900 cycles; measured by duplicating one kind at a time)
         Place pla;
-        const int sK_ = pla.at(U * 2 * NS), sKy_ = pla.at(U * 2 * N), sKyy_ = pla.at(U);
-        WG_FOR_AT(t, U * 2 * NS, sK_) {          // entries of K_i and X_i (packed lower, both halves)
-            const int u = t / (2 * NS), q = t - u * (2 * NS), i = q / NS, pq = q - i * NS;
-            double *un = UN(u);
-            double *K = un + W::K, *X = un + W::X;
-            const double *Da = un + oR1, *Db = Da + m2;
-            const bool blk = u > 0, out = blk && side_of(u);
-            int k, l;
-            if constexpr (N == 2) { k = pq > 0; l = pq > 1; }      // packed lower index of a 2 x 2 block: (0,0) (1,0) (1,1)
-            else tri_decode(pq, k, l);
-            double sk = 0, sx = 0;
-            if constexpr (BOX) {
-                if (k == l) {          // facets k and k + N carry e_k e_k'; every other product is zero
-                    sk = (Da[i * m + k] + Db[i * m + k]) + (Da[i * m + k + N] + Db[i * m + k + N]);
-                    sx = Db[i * m + k] + Db[i * m + k + N];
-                }
-            } else {
-#pragma unroll 4
+        const int sK_ = pla.at(BOX ? U * 2 * N : U * 2 * NS), sKy_ = BOX ? 0 : pla.at(U * 2 * N), sKyy_ = pla.at(U);
+        (void)sKy_;
+        if constexpr (BOX) {
+            // structured forms: one task per (unit, half, coordinate k) -- the diagonal entries of K_h and X_h and the k-th entries
+            // of the y column / y row, from the two facets +-e_k
+            WG_FOR_AT(t, U * 2 * N, sK_) {
+                const int u = t / (2 * N), ik = t - u * (2 * N), i = ik / N, k = ik - i * N;
+                double *un = UN(u);
+                const double *Da = un + oR1, *Db = Da + m2;
+                const bool blk = u > 0, out = blk && side_of(u);
+                const double dp = Da[i * m + k] + Db[i * m + k], dn = Da[i * m + k + N] + Db[i * m + k + N];
+                const double bp = BC[k], bn = -BC[k + N];       // b_j a_j[k] of the two facets on coordinate k
+                double sk = dp + dn;
+                sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; if (prox) sk += sm[W::PQ + NX + i * N + k];
+                un[W::KD + ik] = sk;
+                un[W::XD + ik] = -(Db[i * m + k] + Db[i * m + k + N]);
+                double sy = -(dp * bp) - dn * bn;
+                if (blk && (i == 0 || out)) sy += rho * CEN[k];
+                if (prox) sy += sm[W::PQ + NX + i * N + k] * CEN[k];
+                un[W::KY + ik] = sy;
+                un[W::XY + ik] = Db[i * m + k] * bp + Db[i * m + k + N] * bn;
+            }
+        } else {
+            WG_FOR_AT(t, U * 2 * NS, sK_) {          // entries of K_i and X_i (packed lower, both halves)
+                const int u = t / (2 * NS), q = t - u * (2 * NS), i = q / NS, pq = q - i * NS;
+                double *un = UN(u);
+                double *K = un + W::K, *X = un + W::X;
+                const double *Da = un + oR1, *Db = Da + m2;
+                const bool blk = u > 0, out = blk && side_of(u);
+                int k, l;
+                if constexpr (N == 2) { k = pq > 0; l = pq > 1; }      // packed lower index of a 2 x 2 block: (0,0) (1,0) (1,1)
+                else tri_decode(pq, k, l);
+                double sk = 0, sx = 0;
+    #pragma unroll 4
                 for (int j = 0; j < m; ++j) {
                     const double aa = A[j * N + k] * A[j * N + l];
                     sk += (Da[i * m + j] + Db[i * m + j]) * aa;
                     sx += Db[i * m + j] * aa;
                 }
+                if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; if (prox) sk += sm[W::PQ + NX + i * N + k]; }
+                K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
+                X[(i * N + k) * NX + i * N + l] = -sx; X[(i * N + l) * NX + i * N + k] = -sx;
+                const int o = (1 - i) * N;      // the two halves are not coupled directly
+                K[(i * N + k) * NW + o + l] = 0.0; K[(i * N + l) * NW + o + k] = 0.0;
+                X[(i * N + k) * NX + o + l] = 0.0; X[(i * N + l) * NX + o + k] = 0.0;
             }
-            if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; if (prox) sk += sm[W::PQ + NX + i * N + k]; }
-            K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
-            X[(i * N + k) * NX + i * N + l] = -sx; X[(i * N + l) * NX + i * N + k] = -sx;
-            const int o = (1 - i) * N;      // the two halves are not coupled directly
-            K[(i * N + k) * NW + o + l] = 0.0; K[(i * N + l) * NW + o + k] = 0.0;
-            X[(i * N + k) * NX + o + l] = 0.0; X[(i * N + l) * NX + o + k] = 0.0;
-        }
-        WG_FOR_AT(t, U * 2 * N, sKy_) {           // y column of K, y row of X
-            const int u = t / (2 * N), ik = t - u * (2 * N), i = ik / N, k = ik - i * N;
-            double *un = UN(u);
-            const double *Da = un + oR1, *Db = Da + m2;
-            const bool blk = u > 0, out = blk && side_of(u);
-            double sk = 0, sx = 0;
-            if constexpr (BOX) {
-                const double bp = BC[k], bn = -BC[k + N];       // b_j a_j[k] of the two facets on coordinate k
-                sk = -((Da[i * m + k] + Db[i * m + k]) * bp) - (Da[i * m + k + N] + Db[i * m + k + N]) * bn;
-                sx = Db[i * m + k] * bp + Db[i * m + k + N] * bn;
-            } else {
-#pragma unroll 4
+            WG_FOR_AT(t, U * 2 * N, sKy_) {           // y column of K, y row of X
+                const int u = t / (2 * N), ik = t - u * (2 * N), i = ik / N, k = ik - i * N;
+                double *un = UN(u);
+                const double *Da = un + oR1, *Db = Da + m2;
+                const bool blk = u > 0, out = blk && side_of(u);
+                double sk = 0, sx = 0;
+    #pragma unroll 4
                 for (int j = 0; j < m; ++j) {
                     const double ba = BC[j] * A[j * N + k];
                     sk -= (Da[i * m + j] + Db[i * m + j]) * ba;
                     sx += Db[i * m + j] * ba;
                 }
+                if (blk && (i == 0 || out)) sk += rho * CEN[k];
+                if (prox) sk += sm[W::PQ + NX + i * N + k] * CEN[k];
+                un[W::K + (i * N + k) * NW + 2 * N] = sk; un[W::K + 2 * N * NW + i * N + k] = sk;
+                un[W::X + 2 * N * NX + i * N + k] = sx;
             }
-            if (blk && (i == 0 || out)) sk += rho * CEN[k];
-            if (prox) sk += sm[W::PQ + NX + i * N + k] * CEN[k];
-            un[W::K + (i * N + k) * NW + 2 * N] = sk; un[W::K + 2 * N * NW + i * N + k] = sk;
-            un[W::X + 2 * N * NX + i * N + k] = sx;
         }
         WG_FOR_AT(u, U, sKyy_) {                   // K_yy
             double *un = UN(u);
@@ -951,7 +1003,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll
                 for (int k = 0; k < 2 * N; ++k) sk += sm[W::PQ + NX + k] * CEN[k < N ? k : k - N] * CEN[k < N ? k : k - N];
             }
-            un[W::K + 2 * N * NW + 2 * N] = sk;
+            if constexpr (BOX) un[W::KYY] = sk; else un[W::K + 2 * N * NW + 2 * N] = sk;
         }
         WG_SYNC();
         WG_STAMP(2);
@@ -972,16 +1024,14 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 double ch = 0;
 #pragma unroll
                 for (int r = 0; r < N; ++r) {
-                    const double dd = un[W::K + (h * N + r) * NW + h * N + r], kr = un[W::K + (h * N + r) * NW + 2 * N];
+                    const double dd = un[W::KD + h * N + r], kr = un[W::KY + h * N + r];
                     const double inv = rsqrt_nr(dd), lr = kr * inv;       // (the pivot of a diagonal block is its entry: no clamp can fire)
-#pragma unroll
-                    for (int c = 0; c < N; ++c) un[W::B + (h * N + r) * NW + h * N + c] = c == r ? inv * inv : 0.0;
-                    un[W::PIV + h * N + r] = lr * inv;
+                    un[W::BD + h * N + r] = inv * inv;
+                    un[W::BW + h * N + r] = lr * inv;
                     ch += lr * lr;
                 }
                 un[W::RV + h] = ch;
-                continue;
-            }
+            } else {
             double a[NS], kv[N], pv[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -1045,9 +1095,31 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 un[W::PIV + h * N + r] = acc;
             }
             un[W::RV + h] = ch;
+            }
         }
         WG_SYNC();
         WG_STAMP(3);
+        if constexpr (BOX) {
+            // 1 / s of the y pivot (every thread of the unit forms it: no region of its own), the last entry of BW, and
+            // BQ = X_e' BW (B_e X_e = diag(BD XD) + BRS BW BQ' is never formed)
+            WG_FOR(t, d * NW) {
+                const int u = 1 + t / NW, c = t - (u - 1) * NW;
+                double *un = UN(u);
+                if (c < 2 * N) un[W::BQ + c] = un[W::BW + c] * un[W::XD + c] - un[W::XY + c];
+                else {
+                    const double kap = un[W::KYY];
+                    double sy = kap - un[W::RV] - un[W::RV + 1];
+                    if (!(sy > CHOL_SKIP * kap)) sy = kap > 0.0 ? CHOL_SKIP * kap : 1.0;
+                    un[W::BRS] = rcp(sy);
+                    un[W::BW + 2 * N] = -1.0;
+                }
+            }
+            WG_SYNC();
+            WG_STAMP(4);
+            { Place plx; te_tasks(plx, false); }     // affine solve, head 1/4
+            WG_SYNC();
+            WG_STAMP(5);
+        } else {
         WG_FOR(t, d * NW * NW) {
             const int u = 1 + t / (NW * NW), ij = t - (u - 1) * (NW * NW), i = ij / NW, j = ij - i * NW;
             double *un = UN(u);
@@ -1066,30 +1138,48 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const int u = 1 + t / (NW * NX), ic = t - (u - 1) * (NW * NX), i = ic / NX, c = ic - i * NX, h = c / N;
             double *un = UN(u);
             double s = un[W::B + i * NW + 2 * N] * un[W::X + 2 * N * NX + c];
-            if constexpr (BOX) s += un[W::B + i * NW + c] * un[W::X + c * NX + c];       // X_e is diagonal in its x part
-            else {
 #pragma unroll
-                for (int k = 0; k < N; ++k) s += un[W::B + i * NW + h * N + k] * un[W::X + (h * N + k) * NX + c];
-            }
+            for (int k = 0; k < N; ++k) s += un[W::B + i * NW + h * N + k] * un[W::X + (h * N + k) * NX + c];
             un[W::K + ic] = s;
         }
         te_tasks(plx, false);            // affine solve, head 1/4
         WG_SYNC();
         WG_STAMP(5);
+        }
         // ================= side sums: Bs, BXs, X'BX, equality residuals =================
         Place plq;
         WG_FOR_AT(t, 2 * NW * NW, plq.at(2 * NW * NW)) {
             const int s = t / (NW * NW), q = t - s * NW * NW;
             double acc2 = 0;
+            if constexpr (BOX) {       // B_e = diag(BD) + BRS BW BW'
+                const int i = q / NW, j = q - i * NW;
 #pragma unroll 4
-            for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::B + q];
+                for (int u = side_lo(s); u <= side_hi(s); ++u) {
+                    const double *un = UN(u);
+                    acc2 += (un[W::BRS] * un[W::BW + i]) * un[W::BW + j];
+                    if (i == j && i < 2 * N) acc2 += un[W::BD + i];
+                }
+            } else {
+#pragma unroll 4
+                for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::B + q];
+            }
             sm[W::BS + t] = acc2;
         }
         WG_FOR_AT(tt, 2 * NW * NX, plq.at(2 * NW * NX)) {
             const int s = tt / (NW * NX), q = tt - s * NW * NX;
             double acc2 = 0;
+            if constexpr (BOX) {       // B_e X_e = diag(BD XD) + BRS BW BQ'
+                const int i = q / NX, c = q - i * NX;
 #pragma unroll 4
-            for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::K + q];
+                for (int u = side_lo(s); u <= side_hi(s); ++u) {
+                    const double *un = UN(u);
+                    acc2 += (un[W::BRS] * un[W::BW + i]) * un[W::BQ + c];
+                    if (i == c) acc2 += un[W::BD + c] * un[W::XD + c];
+                }
+            } else {
+#pragma unroll 4
+                for (int u = side_lo(s); u <= side_hi(s); ++u) acc2 += UN(u)[W::K + q];
+            }
             sm[W::BXS + tt] = acc2;
         }
         WG_FOR_AT(tp, 2 * NX * NX, plq.at(2 * NX * NX)) {      // sum_e X_e' (B_e X_e), the blocks in two halves (shorter chains)
@@ -1099,20 +1189,29 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll 2
             for (int u = ulo; u <= uhi; ++u) {
                 const double *un = UN(u);
-                if constexpr (BOX) acc2 += un[W::X + r * NX + r] * un[W::K + r * NX + c];
-                else {
+                if constexpr (BOX) {       // X_e' B_e X_e = diag(XD^2 BD) + BRS BQ BQ'
+                    acc2 += (un[W::BRS] * un[W::BQ + r]) * un[W::BQ + c];
+                    if (r == c) acc2 += (un[W::XD + r] * un[W::XD + r]) * un[W::BD + r];
+                } else {
 #pragma unroll
                     for (int k = 0; k < N; ++k) acc2 += un[W::X + (h * N + k) * NX + r] * un[W::K + (h * N + k) * NX + c];
+                    acc2 += un[W::X + 2 * N * NX + r] * un[W::K + 2 * N * NX + c];
                 }
-                acc2 += un[W::X + 2 * N * NX + r] * un[W::K + 2 * N * NX + c];
             }
             sm[W::XBX + tp] = acc2;
         }
         WG_FOR_AT(tt, NX * N, plq.at(NX * N)) {                 // sum over ALL units of the x-x coupling (same half only)
             const int r = tt / N, c = (r / N) * N + (tt - r * N);
             double acc2 = 0;
+            if constexpr (BOX) {
+                if (c == r) {
 #pragma unroll 4
-            for (int u = 0; u <= d; ++u) acc2 += UN(u)[W::X + r * NX + c];
+                    for (int u = 0; u <= d; ++u) acc2 += UN(u)[W::XD + r];
+                }
+            } else {
+#pragma unroll 4
+                for (int u = 0; u <= d; ++u) acc2 += UN(u)[W::X + r * NX + c];
+            }
             sm[W::XS + tt] = acc2;
         }
         WG_FOR_AT(tt, 2 * NW, plq.at(2 * NW)) {
@@ -1163,10 +1262,18 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // assembly through a scratch matrix would use (that was one more region: 2 200 cycles against ~1 400).
         {
             const double *YS0 = sm + W::BS, *YS1 = sm + W::BS + NW * NW, *u0 = UN(0);
-            auto zx = [&](int i, int c) { return u0[W::X + i * NX + c] + YS0[i * NX + c] + YS1[i * NX + c]; };
+            auto x0 = [&](int i, int c) {       // X of the border unit
+                if constexpr (BOX) return i == c ? u0[W::XD + c] : (i == 2 * N ? u0[W::XY + c] : 0.0);
+                else return u0[W::X + i * NX + c];
+            };
+            auto k0 = [&](int hi, int lo) {     // K of the border unit, lower triangle
+                if constexpr (BOX) return hi == lo ? (hi < 2 * N ? u0[W::KD + hi] : u0[W::KYY]) : (hi == 2 * N ? u0[W::KY + lo] : 0.0);
+                else return u0[W::K + hi * NW + lo];
+            };
+            auto zx = [&](int i, int c) { return x0(i, c) + YS0[i * NX + c] + YS1[i * NX + c]; };
             auto zz = [&](int i, int k) {       // symmetric; the lower-triangle copy is the one used
                 const int hi = i > k ? i : k, lo = i > k ? k : i;
-                return u0[W::K + hi * NW + lo] + sm[W::BSI + hi * NW + lo] + sm[W::BSI + NW * NW + hi * NW + lo];
+                return k0(hi, lo) + sm[W::BSI + hi * NW + lo] + sm[W::BSI + NW * NW + hi * NW + lo];
             };
             Place plm;
             WG_FOR_AT(t, NX * (NX + 1) / 2, plm.at(NX * (NX + 1) / 2)) {        // x-x

@@ -149,7 +149,7 @@ template <int N, class T> hipError_t set_lds(int lds_bytes)
 
 }  // namespace
 
-int gcsadmm_wg_lds_bytes(int n, int units, int facets) { return 8 * gcs_wg::wg_lds_doubles_n(n, units, facets); }
+int gcsadmm_wg_lds_bytes(int n, int units, int facets, bool box) { return 8 * gcs_wg::wg_lds_doubles_n(n, units, facets, box); }
 
 hipError_t gcsadmm_wg_set_lds(int n, int dtype, int lds_bytes)
 {

@@ -28,7 +28,7 @@ static void run_all(const gcs_wg::WgArgs<double> &a, double rho, double mu_scale
     for (int w = 0; w < a.n_vtx; ++w) {
         std::fill(smem.begin(), smem.end(), 0.0 / 0.0);
         int st = -9, it = 0;
-        if (g_emu_box) gcs_wg::wg_solve_vertex<N, double, true>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
+        if (g_emu_box && N > 2) gcs_wg::wg_solve_vertex<N, double, (N > 2)>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
         else gcs_wg::wg_solve_vertex<N, double, false>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
         status[a.vtx[w]] = st; iters[a.vtx[w]] = it;
         a.counters[0] += st != 0; a.counters[1] += it;
@@ -56,7 +56,7 @@ extern "C" int EMU_FN(int n, int V, int E, int NI, const int *inc_ptr, const int
         status[v] = 0; iters[v] = 0;
         if (is_generic[v]) {
             vtx.push_back(v);
-            lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, d + 1, poly_ptr[v + 1] - poly_ptr[v]));
+            lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, d + 1, poly_ptr[v + 1] - poly_ptr[v], g_emu_box));
         }
     }
     std::vector<double> bc(poly_ptr[V]);
@@ -96,7 +96,7 @@ extern "C" int EMU_PROX(int n, int V, const int *poly_ptr, const double *poly_A,
         status[v] = 0; iters[v] = 0;
         if (v == src || v == dst) continue;
         vtx.push_back(v);
-        lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, 1, poly_ptr[v + 1] - poly_ptr[v]));
+        lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, 1, poly_ptr[v + 1] - poly_ptr[v], g_emu_box));
     }
     std::vector<double> bc(poly_ptr[V]);
     for (int v = 0; v < V; ++v)
