@@ -1148,11 +1148,15 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         // ================= side sums: Bs, BXs, X'BX, equality residuals =================
         Place plq;
-        WG_FOR_AT(t, 2 * NW * NW, plq.at(2 * NW * NW)) {
-            const int s = t / (NW * NW), q = t - s * NW * NW;
+        // (B_s and X'BX are symmetric and only their lower triangles are read -- by the side factorisation and by the border assembly)
+        constexpr int NWT = NW * (NW + 1) / 2, NXT = NX * (NX + 1) / 2;
+        WG_FOR_AT(t0, 2 * NWT, plq.at(2 * NWT)) {
+            const int s = t0 / NWT;
+            int i, j;
+            tri_decode(t0 - s * NWT, i, j);
+            const int q = i * NW + j, t = s * NW * NW + q;
             double acc2 = 0;
             if constexpr (BOX) {       // B_e = diag(BD) + BRS BW BW'
-                const int i = q / NW, j = q - i * NW;
 #pragma unroll 4
                 for (int u = side_lo(s); u <= side_hi(s); ++u) {
                     const double *un = UN(u);
@@ -1182,8 +1186,12 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             }
             sm[W::BXS + tt] = acc2;
         }
-        WG_FOR_AT(tp, 2 * NX * NX, plq.at(2 * NX * NX)) {      // sum_e X_e' (B_e X_e), the blocks in two halves (shorter chains)
-            const int part = tp / (NX * NX), tt = tp - part * NX * NX, r = tt / NX, c = tt - r * NX, h = r / N;
+        WG_FOR_AT(tp0, 2 * NXT, plq.at(2 * NXT)) {      // sum_e X_e' (B_e X_e), the blocks in two halves (shorter chains)
+            const int part = tp0 / NXT;
+            int r, c;
+            tri_decode(tp0 - part * NXT, r, c);
+            const int tp = part * NX * NX + r * NX + c, h = r / N;
+            (void)h;
             const int ulo = part ? 1 + d / 2 : 1, uhi = part ? d : d / 2;
             double acc2 = 0;
 #pragma unroll 2
@@ -1248,7 +1256,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         } else {
             // no blocks (prox configuration): the side matrices and everything derived from them are zero -- Bs and BXs
             // already are (empty sums), the formulas below then need Bs^{-1} := 0 and Y_s := 0 (= the Bs buffer as it stands)
-            WG_FOR(t, 2 * NW * NW) sm[W::BSI + t] = 0.0;
+            WG_FOR(t, 2 * NW * NW) { sm[W::BSI + t] = 0.0; sm[W::BS + t] = 0.0; }      // (Bs: only its lower triangle was written)
             WG_SYNC();
         }
         v_tasks(ply);                    // affine solve, head 3/4
