@@ -65,6 +65,8 @@ static_assert(sizeof(counted) == sizeof(double), "counted must alias double arra
 #include "vertex_wg.h"
 #undef double
 
+static bool g_box = false;      // count the BOX instantiation (what the library runs when every vertex is a canonical box and n > 2)
+
 template <int N>
 static void run_all(const gcs_wg::WgArgs<counted> &a, counted rho, counted mu_scale, int lds, long long *iters)
 {
@@ -72,7 +74,8 @@ static void run_all(const gcs_wg::WgArgs<counted> &a, counted rho, counted mu_sc
     for (int w = 0; w < a.n_vtx; ++w) {
         std::fill(smem.begin(), smem.end(), counted(0.0 / 0.0));
         int st = -9, it = 0;
-        gcs_wg::wg_solve_vertex<N, counted>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
+        if (g_box && N > 2) gcs_wg::wg_solve_vertex<N, counted, (N > 2)>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
+        else gcs_wg::wg_solve_vertex<N, counted, false>(a, a.vtx[w], rho, mu_scale, smem.data(), st, it);
         *iters += it;
     }
 }
@@ -86,12 +89,21 @@ extern "C" int wg_count_vertex_step(int n, int V, int E, int NI, const int *inc_
     if (n != 2 && n != 3 && n != 6) return 1;
     std::vector<int> deg_in(V, 0), vtx;
     int lds = 0;
+    // the same rule as gcsadmm_create (canonical_box.h): BOX instantiation when every counted vertex is a canonical box, n > 2
+    g_box = n > 2;
+    for (int v = 0; v < V && g_box; ++v) {
+        const int m = poly_ptr[v + 1] - poly_ptr[v];
+        if (m != 2 * n) { g_box = false; break; }
+        for (int j = 0; j < m && g_box; ++j)
+            for (int k = 0; k < n; ++k)
+                if (poly_A[((size_t)poly_ptr[v] + j) * n + k] != ((j % n) == k ? (j < n ? 1.0 : -1.0) : 0.0)) { g_box = false; break; }
+    }
     for (int v = 0; v < V; ++v) {
         for (int k = inc_ptr[v]; k < inc_ptr[v + 1]; ++k) deg_in[v] += !inc_out[k];
         const int d = inc_ptr[v + 1] - inc_ptr[v];
         if (!(v == src || v == dst || deg_in[v] == 0 || d - deg_in[v] == 0)) {
             vtx.push_back(v);
-            lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, d + 1, poly_ptr[v + 1] - poly_ptr[v]));
+            lds = std::max(lds, gcs_wg::wg_lds_doubles_n(n, d + 1, poly_ptr[v + 1] - poly_ptr[v], g_box));
         }
     }
     std::vector<counted> bc(poly_ptr[V]), A((size_t)poly_ptr[V] * n), cen((size_t)V * n), ze((size_t)(2 * n + 1) * E), m_((size_t)(2 * n + 1) * NI);
