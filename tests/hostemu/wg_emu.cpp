@@ -35,7 +35,7 @@ static void run_all(const gcs_wg::WgArgs<double> &a, double rho, double mu_scale
     }
 }
 
-extern "C" int EMU_LDS(int n, int U, int m) { return gcs_wg::wg_lds_doubles_n(n, U, m); }
+extern "C" int EMU_LDS(int n, int U, int m) { return gcs_wg::wg_lds_doubles_n(n, U, m, g_emu_box); }      // (layout of the mode set by EMU_BOX)
 // 1: the following steps run the BOX instantiation of the program (every polytope must be a canonical box: canonical_box.h)
 extern "C" void EMU_BOX(int on) { g_emu_box = on != 0; }
 

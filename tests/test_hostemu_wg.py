@@ -124,5 +124,10 @@ def test_lds_budget_of_the_named_configs(libs):
     (160 KB); benchmark4's largest vertex and a degree-80 box vertex must fit one."""
     fwd, _ = libs
     assert 8 * fwd.wg_emu_lds_doubles(6, 9, 12) <= 80 * 1024
+    fwd.wg_emu_set_box(1)
+    try:      # the BOX instantiation's structured unit layout: THREE workgroups of config 5 per CU (DESIGN.md section 4)
+        assert 3 * 8 * fwd.wg_emu_lds_doubles(6, 9, 12) <= 160 * 1024
+    finally:
+        fwd.wg_emu_set_box(0)
     assert 8 * fwd.wg_emu_lds_doubles(2, 11, 7) <= 32 * 1024
     assert 8 * fwd.wg_emu_lds_doubles(2, 81, 4) <= 160 * 1024
