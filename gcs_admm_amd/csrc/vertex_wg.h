@@ -466,6 +466,21 @@ template <int Q> GCS_HD void soc_apply_W2(const double *wb, double eta, const do
 // one vertex sub-problem.  `sm` is the workgroup's LDS (wg_lds_doubles doubles).  Returns (to every thread) the
 // solver status (0 = converged) and the number of interior-point iterations through status_out / iters_out.
 // ---------------------------------------------------------------------------------------------------------------
+// The facet rows of the sub-problem as tasks of a region (inside wg_solve_vertex: uses its locals).  Generic: one task per row.  BOX: one
+// task per (unit, half, coordinate k) runs the FOUR rows on that coordinate -- types a and b of the facets +e_k and -e_k -- back to
+// back: they share their operands, the four reciprocal chains overlap, and 2n(d+1) tasks fit one pass where 8n(d+1) rows need two.
+// Declares u, ro, ty, i, j for the body.
+#define WG_ROWS_BEGIN(pl)                                                                                                      \
+    WG_FOR_AT(rt_, (BOX ? U * 2 * N : RT), (pl).at(BOX ? U * 2 * N : RT)) {                                                    \
+        _Pragma("unroll") for (int rq_ = 0; rq_ < (BOX ? 4 : 1); ++rq_) {                                                      \
+            int u, ro, ty, i, j;                                                                                               \
+            if constexpr (BOX) {                                                                                               \
+                u = rt_ / (2 * N);                                                                                             \
+                const int ik_ = rt_ - u * (2 * N);                                                                             \
+                i = ik_ / N; j = (ik_ - i * N) + (rq_ & 1) * N; ty = rq_ >> 1; ro = ty * m2 + i * m + j;                       \
+            } else row_decode(rt_, u, ro, ty, i, j);
+#define WG_ROWS_END() }}
+
 // BOX: the vertex's polytope is an axis-aligned box with its facets in the canonical order [+e_0 .. +e_{N-1}, -e_0 .. -e_{N-1}] (the
 // lattice configurations; checked by the caller, canonical_box.h).  Facet j then has the single non-zero entry sg_j = +-1 at
 // k_j = j mod N: every facet-row dot product is one term, K_h and the x-coupling X_e of a unit are DIAGONAL (plus the y row /
@@ -806,9 +821,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // ================= rows: slacks, duals at the start, D = l/s, complementarity =================
         double acc = 0.0; int bad = 0;
         Place plr;
-        WG_FOR_AT(r, RT, plr.at(RT)) {
-            int u, ro, ty, i, j;
-            row_decode(r, u, ro, ty, i, j);
+        WG_ROWS_BEGIN(plr)
             double *un = UN(u);
             const double s = row_slack(un, ty, i, j);
             const double is = rcp1(s);
@@ -817,7 +830,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             un[oR1 + ro] = l * is;
             acc += s * l;
             if (!(s > 0.0)) bad = 1;
-        }
+        WG_ROWS_END()
         WG_FOR_AT(u, U, plr.at(U)) {      // bounds 0 <= y <= 1 of every unit
             double *un = UN(u);
             const double yy = un[W::P + 2 * N], s5 = yy, s6 = 1.0 - yy;
@@ -1325,9 +1338,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // rows: step bound, mu_aff sums, ds_a dl_a
         double rmax = 0.0, c1 = 0.0, c2 = 0.0;
         Place plb;
-        WG_FOR_AT(r, RT, plb.at(RT)) {
-            int u, ro, ty, i, j;
-            row_decode(r, u, ro, ty, i, j);
+        WG_ROWS_BEGIN(plb)
             double *un = UN(u);
             const double s = row_slack(un, ty, i, j), l = un[oLAM + ro], is = rcp1(s);
             const double ds = row_ds(un, ty, i, j);
@@ -1336,7 +1347,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             c1 += s * dl + l * ds; c2 += ds * dl;
             un[oR1 + ro] = ds * dl;
             un[oR2 + ro] = is;           // kappa = (sigma mu - ds_a dl_a) / s is formed where it is used (G'kappa, final direction)
-        }
+        WG_ROWS_END()
         WG_FOR_AT(u, U, plb.at(U)) {
             double *un = UN(u);
             const double yy = un[W::P + 2 * N], dy = un[W::DW + 2 * N];
@@ -1438,9 +1449,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // ================= final direction: dual directions, step bound =================
         rmax = 0.0;
         Place pld;
-        WG_FOR_AT(r, RT, pld.at(RT)) {
-            int u, ro, ty, i, j;
-            row_decode(r, u, ro, ty, i, j);
+        WG_ROWS_BEGIN(pld)
             double *un = UN(u);
             const double s = row_slack(un, ty, i, j), l = un[oLAM + ro];
             const double ip = rcp1(s * l), is = l * ip, il = s * ip;      // 1/s and 1/l from one reciprocal
@@ -1448,7 +1457,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const double dl = (sigmu - un[oR1 + ro]) * un[oR2 + ro] - l - (l * is) * ds;      // kappa - l - (l / s) ds
             un[oR2 + ro] = dl;
             rmax = fmax(rmax, fmax(-ds * is, -dl * il));
-        }
+        WG_ROWS_END()
         WG_FOR_AT(u, U, pld.at(U)) {
             double *un = UN(u);
             const double yy = un[W::P + 2 * N], dy = un[W::DW + 2 * N];
