@@ -466,19 +466,40 @@ template <int Q> GCS_HD void soc_apply_W2(const double *wb, double eta, const do
 // one vertex sub-problem.  `sm` is the workgroup's LDS (wg_lds_doubles doubles).  Returns (to every thread) the
 // solver status (0 = converged) and the number of interior-point iterations through status_out / iters_out.
 // ---------------------------------------------------------------------------------------------------------------
-// The facet rows of the sub-problem as tasks of a region (inside wg_solve_vertex: uses its locals).  Generic: one task per row.  BOX: one
-// task per (unit, half, coordinate k) runs the FOUR rows on that coordinate -- types a and b of the facets +e_k and -e_k -- back to
-// back: they share their operands, the four reciprocal chains overlap, and 2n(d+1) tasks fit one pass where 8n(d+1) rows need two.
-// Declares u, ro, ty, i, j for the body.
-#define WG_ROWS_BEGIN(pl)                                                                                                      \
-    WG_FOR_AT(rt_, (BOX ? U * 2 * N : RT), (pl).at(BOX ? U * 2 * N : RT)) {                                                    \
-        _Pragma("unroll") for (int rq_ = 0; rq_ < (BOX ? 4 : 1); ++rq_) {                                                      \
-            int u, ro, ty, i, j;                                                                                               \
-            if constexpr (BOX) {                                                                                               \
-                u = rt_ / (2 * N);                                                                                             \
-                const int ik_ = rt_ - u * (2 * N);                                                                             \
-                i = ik_ / N; j = (ik_ - i * N) + (rq_ & 1) * N; ty = rq_ >> 1; ro = ty * m2 + i * m + j;                       \
-            } else row_decode(rt_, u, ro, ty, i, j);
+// The facet rows of the sub-problem as tasks of a region (inside wg_solve_vertex: uses its locals).  A task takes the rows that SHARE
+// their operands and runs them back to back (their reciprocal chains overlap):
+//   generic: (unit, half, facet j): the two rows of the facet, type a (s = b y - a.p) and type b (s = b (1 - y) - a.(x - p)): one
+//            pass over the facet's normal gives both dot products -- 2m(d+1) tasks instead of 4m(d+1) rows (benchmark4's heaviest
+//            vertex: 154 tasks in one pass instead of 308 rows in two);
+//   BOX:     (unit, half, coordinate k): the four rows on that coordinate, types a and b of the facets +e_k and -e_k -- 2n(d+1) tasks.
+// Declares for the body: u, un, i, j, ty, ro (offset in the unit's row arrays), s (slack at the iterate) and, with DS, ds (slack
+// direction for the direction DW of the unit / DX):  ds_a = b dy - a.dp ;  ds_b = -b dy - a.(dx - dp).
+#define WG_ROWS_BEGIN_(pl, DS)                                                                                                 \
+    WG_FOR_AT(rt_, (BOX ? U * 2 * N : U * m2), (pl).at(BOX ? U * 2 * N : U * m2)) {                                            \
+        int u, i, jk_;                                                                                                         \
+        if constexpr (BOX) { u = rt_ / (2 * N); const int ik_ = rt_ - u * (2 * N); i = ik_ / N; jk_ = ik_ - i * N; }           \
+        else { u = fdiv(rt_, inv_m2); const int rem_ = rt_ - u * m2; i = rem_ >= m; jk_ = rem_ - i * m; }                      \
+        double *un = UN(u);                                                                                                    \
+        double ap_ = 0, ax_ = 0, adp_ = 0, adx_ = 0;                                                                           \
+        if constexpr (BOX) {                                                                                                   \
+            ap_ = un[W::P + i * N + jk_]; ax_ = sm[W::XV + i * N + jk_];                                                       \
+            if (DS) { adp_ = un[W::DW + i * N + jk_]; adx_ = sm[W::DX + i * N + jk_]; }                                        \
+        } else {                                                                                                               \
+            _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_) {                                                                 \
+                const double a_ = A[jk_ * N + k_];                                                                             \
+                ap_ += a_ * un[W::P + i * N + k_]; ax_ += a_ * sm[W::XV + i * N + k_];                                         \
+                if (DS) { adp_ += a_ * un[W::DW + i * N + k_]; adx_ += a_ * sm[W::DX + i * N + k_]; }                          \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        const double yy_ = un[W::P + 2 * N], dy_ = DS ? un[W::DW + 2 * N] : 0.0;                                               \
+        _Pragma("unroll") for (int rq_ = 0; rq_ < (BOX ? 4 : 2); ++rq_) {                                                      \
+            const int ty = BOX ? rq_ >> 1 : rq_, j = BOX ? jk_ + (rq_ & 1) * N : jk_, ro = ty * m2 + i * m + j;                \
+            const double sg_ = (BOX && (rq_ & 1)) ? -1.0 : 1.0, b_ = BC[j];                                                    \
+            const double s = ty == 0 ? b_ * yy_ - sg_ * ap_ : b_ * (1.0 - yy_) - sg_ * (ax_ - ap_);                            \
+            const double ds = ty == 0 ? b_ * dy_ - sg_ * adp_ : -(b_ * dy_) - sg_ * (adx_ - adp_);                             \
+            (void)ds;
+#define WG_ROWS_BEGIN(pl) WG_ROWS_BEGIN_(pl, false)
+#define WG_ROWS_BEGIN_DS(pl) WG_ROWS_BEGIN_(pl, true)
 #define WG_ROWS_END() }}
 
 // BOX: the vertex's polytope is an axis-aligned box with its facets in the canonical order [+e_0 .. +e_{N-1}, -e_0 .. -e_{N-1}] (the
@@ -499,7 +520,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     const int p0 = a.poly_ptr[v], m = a.poly_ptr[v + 1] - p0;
     const int U = d + 1, R = 4 * m, RT = U * R, m2 = 2 * m;
     const int US = W::unit_stride(m);
-    const float inv_R = 1.0f / (float)R;
+    const float inv_R = 1.0f / (float)R, inv_m2 = 1.0f / (float)m2;
     auto UN = [&](int u) -> double * { return sm + W::FIXED + u * US; };       // base of unit u
     const int oLAM = W::ROWS, oR1 = W::ROWS + R, oR2 = W::ROWS + 2 * R;   // facet-row arrays of a unit: duals, two work arrays
     double *const PA = sm + W::FIXED + pad2(U * US);
@@ -554,44 +575,6 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     WG_SYNC();
 
     WG_STAMP(0);
-    // facet row r of the sub-problem -> (unit, offset inside the unit's row arrays, type a/b, half, facet)
-    auto row_decode = [&](int r, int &u, int &ro, int &ty, int &i, int &j) {
-        u = fdiv(r, inv_R);
-        ro = r - u * R;
-        int rem = ro;
-        ty = rem >= m2; rem -= ty * m2;
-        i = rem >= m; j = rem - i * m;
-    };
-    // slack of a row at the current iterate (recomputed where needed: cheaper than 4m more doubles of LDS per unit, which
-    // is what decides how many workgroups a CU holds at n = 6): s_a = b y - a.p_i ; s_b = b (1 - y) - a.(x_i - p_i)
-    auto row_slack = [&](const double *un, int ty, int i, int j) {
-        double ap = 0, ax = 0;
-        if constexpr (BOX) {
-            const int k = j >= N ? j - N : j;
-            ap = j >= N ? -un[W::P + i * N + k] : un[W::P + i * N + k];
-            ax = j >= N ? -sm[W::XV + i * N + k] : sm[W::XV + i * N + k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; ++k) { ap += A[j * N + k] * un[W::P + i * N + k]; ax += A[j * N + k] * sm[W::XV + i * N + k]; }
-        }
-        const double yy = un[W::P + 2 * N], b = BC[j];
-        return ty == 0 ? b * yy - ap : b * (1.0 - yy) - (ax - ap);
-    };
-    // slack direction of a row for the direction (DW of its unit, DX): ds_a = b dy - a.dp_i ; ds_b = -b dy - a.(dx_i - dp_i)
-    auto row_ds = [&](const double *un, int ty, int i, int j) {
-        double adp = 0, adx = 0;
-        if constexpr (BOX) {
-            const int k = j >= N ? j - N : j;
-            adp = j >= N ? -un[W::DW + i * N + k] : un[W::DW + i * N + k];
-            adx = j >= N ? -sm[W::DX + i * N + k] : sm[W::DX + i * N + k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; ++k) { adp += A[j * N + k] * un[W::DW + i * N + k]; adx += A[j * N + k] * sm[W::DX + i * N + k]; }
-        }
-        const double bdy = BC[j] * un[W::DW + 2 * N];
-        return ty == 0 ? bdy - adp : -bdy - (adx - adp);
-    };
-
     // gradient entry k of unit u for the Newton right-hand side: smooth part G0, plus (corrector solve) G'kappa of the unit's
     // facet rows and, on unit 0, the cone's kappa (-ks on z1, +ks on z2)
     auto gval = [&](const double *un, int u, int k, bool wk) {
@@ -822,8 +805,6 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         double acc = 0.0; int bad = 0;
         Place plr;
         WG_ROWS_BEGIN(plr)
-            double *un = UN(u);
-            const double s = row_slack(un, ty, i, j);
             const double is = rcp1(s);
             if (it == 0) un[oLAM + ro] = is;
             const double l = un[oLAM + ro];
@@ -1338,10 +1319,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // rows: step bound, mu_aff sums, ds_a dl_a
         double rmax = 0.0, c1 = 0.0, c2 = 0.0;
         Place plb;
-        WG_ROWS_BEGIN(plb)
-            double *un = UN(u);
-            const double s = row_slack(un, ty, i, j), l = un[oLAM + ro], is = rcp1(s);
-            const double ds = row_ds(un, ty, i, j);
+        WG_ROWS_BEGIN_DS(plb)
+            const double l = un[oLAM + ro], is = rcp1(s);
             const double q = ds * is, dl = -l - l * q;          // dl / l = -1 - ds / s
             rmax = fmax(rmax, fmax(-q, 1.0 + q));
             c1 += s * dl + l * ds; c2 += ds * dl;
@@ -1449,11 +1428,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // ================= final direction: dual directions, step bound =================
         rmax = 0.0;
         Place pld;
-        WG_ROWS_BEGIN(pld)
-            double *un = UN(u);
-            const double s = row_slack(un, ty, i, j), l = un[oLAM + ro];
+        WG_ROWS_BEGIN_DS(pld)
+            const double l = un[oLAM + ro];
             const double ip = rcp1(s * l), is = l * ip, il = s * ip;      // 1/s and 1/l from one reciprocal
-            const double ds = row_ds(un, ty, i, j);
             const double dl = (sigmu - un[oR1 + ro]) * un[oR2 + ro] - l - (l * is) * ds;      // kappa - l - (l / s) ds
             un[oR2 + ro] = dl;
             rmax = fmax(rmax, fmax(-ds * is, -dl * il));
