@@ -1383,33 +1383,29 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             for (int i = 0; i < Q; ++i) SOC[SO::KS + i] = smd * (i == 0 ? ss[0] : -ss[i]) - a1[i];
             SC[SC_GT] = 1.0 - SOC[SO::KS];
         }
-        // G' kappa per unit: own unknowns (GU) and the x part (GX); one loop per kind of task (uniform wavefronts)
+        // G' kappa per unit: own unknowns (GU) and the x part (GX).  One task per (unit, half, coordinate) forms both entries: they
+        // run over the same rows (kappa_a and kappa_b of every facet), so one pass over the row arrays serves both
         Place plg;
         WG_FOR_AT(t, U * 2 * N, plg.at(U * 2 * N)) {
             const int u = t / (2 * N), q = t - u * (2 * N), i = q / N, k = q - i * N;
             double *un = UN(u);
             const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
-            double s = 0;
+            double su = 0, sx = 0;
             if constexpr (BOX) {
                 const int jp = i * m + k, jn = jp + N;
-                s = ((sigmu - ea[jp]) * ia[jp] - (sigmu - eb[jp]) * ib[jp]) - ((sigmu - ea[jn]) * ia[jn] - (sigmu - eb[jn]) * ib[jn]);
+                const double kbp = (sigmu - eb[jp]) * ib[jp], kbn = (sigmu - eb[jn]) * ib[jn];
+                su = ((sigmu - ea[jp]) * ia[jp] - kbp) - ((sigmu - ea[jn]) * ia[jn] - kbn);
+                sx = kbp - kbn;
             } else {
 #pragma unroll 4
-                for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - ea[i * m + j]) * ia[i * m + j] - (sigmu - eb[i * m + j]) * ib[i * m + j]);
+                for (int j = 0; j < m; ++j) {
+                    const double kb = (sigmu - eb[i * m + j]) * ib[i * m + j], aj = A[j * N + k];
+                    su += aj * ((sigmu - ea[i * m + j]) * ia[i * m + j] - kb);
+                    sx += aj * kb;
+                }
             }
-            un[W::GU + q] = s;
-        }
-        WG_FOR_AT(t, U * NX, plg.at(U * NX)) {
-            const int u = t / NX, c = t - u * NX, i = c / N, k = c - i * N;
-            double *un = UN(u);
-            const double *eb = un + oR1 + m2, *ib = un + oR2 + m2;
-            double s = 0;
-            if constexpr (BOX) s = (sigmu - eb[i * m + k]) * ib[i * m + k] - (sigmu - eb[i * m + k + N]) * ib[i * m + k + N];
-            else {
-#pragma unroll 4
-                for (int j = 0; j < m; ++j) s += A[j * N + k] * ((sigmu - eb[i * m + j]) * ib[i * m + j]);
-            }
-            un[W::GX + c] = s;
+            un[W::GU + q] = su;
+            un[W::GX + q] = sx;
         }
         WG_FOR_AT(u, U, plg.at(U)) {
             double *un = UN(u);
