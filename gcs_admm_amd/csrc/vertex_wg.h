@@ -518,9 +518,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     const int lo = a.inc_ptr[v], d = prox ? 0 : a.inc_ptr[v + 1] - lo, d_in = prox ? 0 : a.deg_in[v], d_out = d - d_in;
     const bool sides = d > 0;
     const int p0 = a.poly_ptr[v], m = a.poly_ptr[v + 1] - p0;
-    const int U = d + 1, R = 4 * m, RT = U * R, m2 = 2 * m;
+    const int U = d + 1, R = 4 * m, m2 = 2 * m;
     const int US = W::unit_stride(m);
-    const float inv_R = 1.0f / (float)R, inv_m2 = 1.0f / (float)m2;
+    const float inv_m2 = 1.0f / (float)m2;
     auto UN = [&](int u) -> double * { return sm + W::FIXED + u * US; };       // base of unit u
     const int oLAM = W::ROWS, oR1 = W::ROWS + R, oR2 = W::ROWS + 2 * R;   // facet-row arrays of a unit: duals, two work arrays
     double *const PA = sm + W::FIXED + pad2(U * US);
@@ -1461,11 +1461,10 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         stalled = alpha < 1e-3;
         // ================= update =================
         Place plu;
-        WG_FOR_AT(r, RT, plu.at(RT)) {
-            const int u = fdiv(r, inv_R), ro = r - u * R;
-            double *un = UN(u);
+        WG_ROWS_BEGIN(plu)       // (the slack the macro offers is unused here: the compiler drops it)
+            (void)s;
             un[oLAM + ro] += alpha * un[oR2 + ro];
-        }
+        WG_ROWS_END()
         WG_FOR_AT(t, U * NW, plu.at(U * NW)) {
             const int u = t / NW, k = t - u * NW;
             double *un = UN(u);
