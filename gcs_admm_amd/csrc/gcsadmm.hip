@@ -398,6 +398,7 @@ struct RcclApi {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     std::string err;
     bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce; }
 };
@@ -416,7 +417,7 @@ RcclApi &rccl()
         }
 #define RCCL_SYM(f) a.f = (decltype(a.f))dlsym(a.lib, "nccl" #f)
         RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommDestroy); RCCL_SYM(GroupStart); RCCL_SYM(GroupEnd);
-        RCCL_SYM(Send); RCCL_SYM(Recv); RCCL_SYM(AllReduce); RCCL_SYM(GetErrorString);
+        RCCL_SYM(Send); RCCL_SYM(Recv); RCCL_SYM(AllReduce); RCCL_SYM(GetErrorString); RCCL_SYM(CommCount);
 #undef RCCL_SYM
         if (!a.ok()) a.err = "librccl lacks an expected symbol";
         return a;
@@ -1123,30 +1124,82 @@ gcsadmm_status gcsadmm_halo_exchange(gcsadmm_handle h, const gcsadmm_state *st, 
     return h->dtype == GCSADMM_F64 ? halo_unpack<double>(h, st, s) : halo_unpack<float>(h, st, s);
 }
 
-gcsadmm_status gcsadmm_run_partitioned(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream)
+// one loop for gcsadmm_run_partitioned and its event-bracketed twin: ev != nullptr records 6 events per iteration on the stream
+// (before / after the vertex step, after the halo exchange, after the edge step, after the all-reduce, after the control step)
+static gcsadmm_status run_partitioned_loop(gcsadmm_handle h, const gcsadmm_state *st, int k, double *trace_dev, hipStream_t s, hipEvent_t *ev)
 {
-    if (!state_ok(h, st) || k < 0) return GCSADMM_ERR_BAD_ARG;
-    if (!h->d_sums6) { h->err = "gcsadmm_attach_comm has not been called"; return GCSADMM_ERR_BAD_ARG; }
-    USE_DEVICE(h);
-    hipStream_t s = (hipStream_t)stream;
     const gcsadmm_params &pp = h->params;
     const ControlParams cp{pp.tau_incr, pp.tau_decr, pp.nu, pp.eps_abs, pp.eps_rel, h->nx, h->nmu, pp.it_rho_limit, pp.max_it};
+    if (!h->comm && h->world > 1) { h->err = "gcsadmm_run_partitioned needs a communicator (gcsadmm_attach_comm with an id)"; return GCSADMM_ERR_BAD_ARG; }
     for (int i = 0; i < k; ++i) {
         gcsadmm_status r;
-        if ((r = gcsadmm_vertex_step(h, st, stream)) != GCSADMM_OK) return r;
-        if ((r = gcsadmm_halo_exchange(h, st, stream)) != GCSADMM_OK) return r;
+        if (ev) HIPCHK(h, hipEventRecord(ev[6 * i + 0], s));
+        if ((r = gcsadmm_vertex_step(h, st, (void *)s)) != GCSADMM_OK) return r;
+        if (ev) HIPCHK(h, hipEventRecord(ev[6 * i + 1], s));
+        if ((r = gcsadmm_halo_exchange(h, st, (void *)s)) != GCSADMM_OK) return r;
+        if (ev) HIPCHK(h, hipEventRecord(ev[6 * i + 2], s));
         r = h->dtype == GCSADMM_F64 ? launch_edge<double>(h, st, h->d_sums6, s, false, nullptr, true)
                                     : launch_edge<float>(h, st, h->d_sums6, s, false, nullptr, true);      // sums + failure count, one launch
         if (r != GCSADMM_OK) return r;
-        if (!h->comm && h->world > 1) { h->err = "gcsadmm_run_partitioned needs a communicator (gcsadmm_attach_comm with an id)"; return GCSADMM_ERR_BAD_ARG; }
+        if (ev) HIPCHK(h, hipEventRecord(ev[6 * i + 3], s));
         const double *reduced = h->d_sums6;
         if (h->comm) {
             NCCLCHK(h, rccl().AllReduce(h->d_sums6, h->d_sums6 + 6, 6, ncclFloat64, ncclSum, (ncclComm_t)h->comm, s));
             reduced = h->d_sums6 + 6;
         }
+        if (ev) HIPCHK(h, hipEventRecord(ev[6 * i + 4], s));
         hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, s, h->d_cb, reduced, cp, h->d_counters, trace_dev, true);
         HIPCHK(h, hipGetLastError());
+        if (ev) HIPCHK(h, hipEventRecord(ev[6 * i + 5], s));
     }
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_run_partitioned(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream)
+{
+    if (!state_ok(h, st) || k < 0) return GCSADMM_ERR_BAD_ARG;
+    if (!h->d_sums6) { h->err = "gcsadmm_attach_comm has not been called"; return GCSADMM_ERR_BAD_ARG; }
+    USE_DEVICE(h);
+    return run_partitioned_loop(h, st, k, trace_dev, (hipStream_t)stream, nullptr);
+}
+
+gcsadmm_status gcsadmm_run_partitioned_timed(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream,
+                                             float *vertex_ms, float *halo_ms, float *edge_ms, float *reduce_ms)
+{
+    if (!state_ok(h, st) || k < 0 || !vertex_ms || !halo_ms || !edge_ms || !reduce_ms) return GCSADMM_ERR_BAD_ARG;
+    if (!h->d_sums6) { h->err = "gcsadmm_attach_comm has not been called"; return GCSADMM_ERR_BAD_ARG; }
+    USE_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    while (h->events.size() < (size_t)6 * k) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->events.push_back(e);
+    }
+    gcsadmm_status r = run_partitioned_loop(h, st, k, trace_dev, s, h->events.data());
+    if (r != GCSADMM_OK) return r;
+    HIPCHK(h, hipStreamSynchronize(s));
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < k; ++i) {
+        float t = 0;
+        HIPCHK(h, hipEventElapsedTime(&t, h->events[6 * i + 0], h->events[6 * i + 1])); acc[0] += t;
+        HIPCHK(h, hipEventElapsedTime(&t, h->events[6 * i + 1], h->events[6 * i + 2])); acc[1] += t;
+        HIPCHK(h, hipEventElapsedTime(&t, h->events[6 * i + 2], h->events[6 * i + 3])); acc[2] += t;
+        HIPCHK(h, hipEventElapsedTime(&t, h->events[6 * i + 3], h->events[6 * i + 5])); acc[3] += t;
+    }
+    *vertex_ms = (float)acc[0]; *halo_ms = (float)acc[1]; *edge_ms = (float)acc[2]; *reduce_ms = (float)acc[3];
+    return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_comm_count(gcsadmm_handle h, int32_t *count)
+{
+    if (!h || !count) return GCSADMM_ERR_BAD_ARG;
+    *count = 0;
+    if (!h->comm) return GCSADMM_OK;        // no communicator attached (single handle, or a host-side transport)
+    if (!rccl().CommCount) { h->err = "librccl lacks ncclCommCount"; return GCSADMM_ERR_HIP; }
+    USE_DEVICE(h);
+    int n = 0;
+    NCCLCHK(h, rccl().CommCount((ncclComm_t)h->comm, &n));
+    *count = n;
     return GCSADMM_OK;
 }
 

@@ -185,7 +185,8 @@ def device_partition(g: GcsGraph, rank: int, world: int, state_dtype: str = "f32
     (gcsadmm_attach_comm).  The 128-byte communicator id is created by rank 0 and distributed with ``torch.distributed``
     (which must be initialised when world > 1; any backend: it only carries the 128 bytes).  The loop itself then runs
     entirely behind the ABI: ``solver.enqueue_partitioned(k)`` / ``solver.solve_partitioned()``.  A single rank (world 1) joins a
-    communicator of its own, so that the loop issues the same RCCL calls at every world size.
+    communicator of its own, so that the loop issues the same RCCL calls at every world size -- unless no RCCL can be loaded, in which
+    case it runs without one (exchange and all-reduce are no-ops for one rank).
     Returns (LocalPartition, DeviceSolver)."""
     import torch
     from .solver import DeviceSolver
@@ -197,7 +198,12 @@ def device_partition(g: GcsGraph, rank: int, world: int, state_dtype: str = "f32
                            edge_counted=part.edge_counted, nx_global=part.nx_global, nmu_global=part.nmu_global, **kw)
         dev.check_halo(rank, world, part.send_idx, part.recv_idx)      # what attach_comm would reject, before anyone enters its collective
         if rank == 0:
-            uid = dev.unique_id()
+            try:
+                uid = dev.unique_id()
+            except Exception:
+                if world > 1:
+                    raise
+                uid = None      # a single rank needs no RCCL: no communicator, the loop's exchange and all-reduce are no-ops
     except Exception as exc:
         err = exc
     if world > 1:

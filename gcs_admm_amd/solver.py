@@ -28,7 +28,7 @@ EXPORTS = ["gcsadmm_create", "gcsadmm_destroy", "gcsadmm_last_error", "gcsadmm_r
            "gcsadmm_cost", "gcsadmm_query", "gcsadmm_unit_iterations", "gcsadmm_vertex_prox",
            # vertex partitions across GPUs (RCCL)
            "gcsadmm_comm_unique_id", "gcsadmm_check_halo", "gcsadmm_attach_comm", "gcsadmm_run_partitioned", "gcsadmm_halo_pack", "gcsadmm_halo_unpack",
-           "gcsadmm_halo_exchange", "gcsadmm_halo_buffers",
+           "gcsadmm_halo_exchange", "gcsadmm_halo_buffers", "gcsadmm_run_partitioned_timed", "gcsadmm_comm_count",
            # graph construction at scale (gcs_admm_amd/scene.py)
            "gcsadmm_polytope_last_error", "gcsadmm_polytope_centers", "gcsadmm_polytope_bounds", "gcsadmm_polytope_overlaps"]
 
@@ -310,6 +310,21 @@ class DeviceSolver:
         with self.torch.cuda.device(self.device):
             self._check(self.lib.gcsadmm_run_partitioned(self.h, C.byref(self.state), int(k), C.c_void_p(self.trace.data_ptr()),
                                                          self._stream()), "gcsadmm_run_partitioned")
+
+    def enqueue_partitioned_timed(self, k: int):
+        """k iterations of the partitioned loop with every stage bracketed by HIP events (collective); device ms per stage"""
+        v, hl, e, r = (C.c_float(0) for _ in range(4))
+        with self.torch.cuda.device(self.device):
+            self._check(self.lib.gcsadmm_run_partitioned_timed(self.h, C.byref(self.state), int(k), C.c_void_p(self.trace.data_ptr()),
+                                                               self._stream(), C.byref(v), C.byref(hl), C.byref(e), C.byref(r)),
+                        "gcsadmm_run_partitioned_timed")
+        return dict(vertex_ms=v.value, halo_ms=hl.value, edge_ms=e.value, reduce_ms=r.value)
+
+    def comm_count(self) -> int:
+        """ranks of the attached RCCL communicator as RCCL reports them (0: none attached)"""
+        n = C.c_int32(0)
+        self._check(self.lib.gcsadmm_comm_count(self.h, C.byref(n)), "gcsadmm_comm_count")
+        return n.value
 
     def halo_pack(self):
         self._check(self.lib.gcsadmm_halo_pack(self.h, C.byref(self.state), self._stream()), "gcsadmm_halo_pack")

@@ -53,7 +53,7 @@ enum { GCSADMM_F64 = 0, GCSADMM_F32 = 1 };
 enum { GCSADMM_RUNNING = -1, GCSADMM_CONVERGED = 0, GCSADMM_MAX_IT = 1, GCSADMM_DIVERGED = 2 };
 
 typedef struct gcsadmm_graph_desc {
-    int32_t n;                       /* space dimension: 2, 3 or 6 */
+    int32_t n;                       /* space dimension: 1 .. 6 */
     int32_t num_vertices;            /* vertices whose sub-problem this handle solves */
     int32_t num_edges;               /* directed edges this handle updates */
     int32_t num_incidences;          /* NI: columns of copy/mu; >= inc_ptr[num_vertices]; the surplus are
@@ -233,6 +233,15 @@ gcsadmm_status gcsadmm_check_halo(gcsadmm_handle h, int32_t rank, int32_t world,
 /* Enqueue up to k full iterations of the partitioned loop (vertex step, halo exchange, edge step, all-reduce, control) with
  * no host synchronisation; every rank must enqueue the same k.  trace_dev as for gcsadmm_run (identical on every rank). */
 gcsadmm_status gcsadmm_run_partitioned(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream);
+
+/* As gcsadmm_run_partitioned with every stage bracketed by HIP events on `stream` (collective: every rank calls it with the same k);
+ * synchronises and returns the summed device time (ms) of the vertex step, the halo exchange (pack, RCCL send/recv, unpack), the
+ * edge step, and the all-reduce + control step.  For measurement (bench.py at N > 1). */
+gcsadmm_status gcsadmm_run_partitioned_timed(gcsadmm_handle h, const gcsadmm_state *st, int32_t k, double *trace_dev, void *stream,
+                                             float *vertex_ms, float *halo_ms, float *edge_ms, float *reduce_ms);
+
+/* Ranks of the attached RCCL communicator as RCCL itself reports them (ncclCommCount); 0 when none is attached. */
+gcsadmm_status gcsadmm_comm_count(gcsadmm_handle h, int32_t *count);
 
 /* The pieces of the halo exchange, for hosts that bring their own transport and for tests: pack the copies to send into the
  * send buffer ([c][columns of peer] per peer, in peer order) / scatter the receive buffer into the ghost columns / both with

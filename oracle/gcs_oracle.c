@@ -1112,15 +1112,18 @@ typedef struct {
 /* ------------------------------------------------------------------ the loop (admm_solver_v3.py:621-733)
  * trace: per iteration 6 doubles (rho after adaptation, pri, dual, eps_pri, eps_dual, inner failures).
  * Returns the iteration count `it` at exit as the reference reports it. */
-int oracle_admm_run(const oracle_graph *G, const oracle_admm_params *ap, const oracle_inner_params *ip,
-                    double *zedge, double *mu, double *copy, double *xv, double *zv, double *yv,
-                    double *trace, int *status_out, long *ipm_iters_total, int nthreads)
+/* the loop from iteration it_start (ap->rho = the penalty in force there; ap->max_it = the last iteration that may run; the trace
+ * row of iteration it is trace + (it - it_start) * 6): a run can be continued by a second call -- bench.py's cpu_baseline times the
+ * same iteration window as the GPU after an untimed advance */
+int oracle_admm_run_from(const oracle_graph *G, const oracle_admm_params *ap, const oracle_inner_params *ip,
+                         double *zedge, double *mu, double *copy, double *xv, double *zv, double *yv,
+                         double *trace, int *status_out, long *ipm_iters_total, int nthreads, int it_start, double *rho_out)
 {
     const int n = G->n;
     const double nx = G->nx_global > 0 ? G->nx_global : (4.0 * n + 1) * (G->V + 2.0 * G->E);
     const double nmu = G->nmu_global > 0 ? G->nmu_global : (4.0 * n + 2) * G->E;
     double rho = ap->rho, mu_scale = 1.0;
-    int it = 1, status = 1; /* 1 = max_it reached, 0 = converged, 2 = diverged */
+    int it = it_start, status = 1; /* 1 = max_it reached, 0 = converged, 2 = diverged */
     while (it <= ap->max_it) {
         int fails = oracle_vertex_step(G, zedge, mu, mu_scale, rho, ip, copy, xv, zv, yv, ipm_iters_total, nthreads);
         double s[5];
@@ -1132,7 +1135,7 @@ int oracle_admm_run(const oracle_graph *G, const oracle_admm_params *ap, const o
         else if (dual >= ap->nu * pri && it < ap->it_rho_limit) { rho *= 1.0 / ap->tau_decr; mu_scale = ap->tau_incr; }
         const double eps_pri = sqrt(nx) * ap->eps_abs + ap->eps_rel * fmax(sqrt(s[2]), sqrt(2.0 * s[3]));
         const double eps_dual = sqrt(nmu) * ap->eps_abs + ap->eps_rel * mu_scale * sqrt(s[4]);
-        double *tr = trace + (size_t)(it - 1) * 6;
+        double *tr = trace + (size_t)(it - it_start) * 6;
         tr[0] = rho; tr[1] = pri; tr[2] = dual; tr[3] = eps_pri; tr[4] = eps_dual; tr[5] = fails;
         if (pri < eps_pri && dual < eps_dual) { status = 0; break; }
         it += 1;
@@ -1140,7 +1143,15 @@ int oracle_admm_run(const oracle_graph *G, const oracle_admm_params *ap, const o
     /* a pending rescale of mu (set on the last executed iteration) is applied so the state is self-consistent */
     if (mu_scale != 1.0) { const size_t N = (size_t)(2 * n + 1) * (G->NI > 0 ? G->NI : 2 * G->E); for (size_t i = 0; i < N; ++i) mu[i] *= mu_scale; }
     *status_out = status;
+    if (rho_out) *rho_out = rho;
     return it;
+}
+
+int oracle_admm_run(const oracle_graph *G, const oracle_admm_params *ap, const oracle_inner_params *ip,
+                    double *zedge, double *mu, double *copy, double *xv, double *zv, double *yv,
+                    double *trace, int *status_out, long *ipm_iters_total, int nthreads)
+{
+    return oracle_admm_run_from(G, ap, ip, zedge, mu, copy, xv, zv, yv, trace, status_out, ipm_iters_total, nthreads, 1, NULL);
 }
 
 /* GCS_utils.py:184-211 on the last iterate */

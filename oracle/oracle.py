@@ -113,6 +113,31 @@ class Oracle:
                     dual_res_seq=np.concatenate([[0.0], trace[:k, 2]]),
                     inner_failures=int(trace[:k, 5].sum()), cost=self.cost())
 
+    def run_from(self, it_start, max_it, rho=1.0, eps_abs=1e-4, eps_rel=1e-3, tau=2.0, nu=10.0, it_rho_limit=100, nthreads=0):
+        """The loop continued from iteration ``it_start`` (``rho`` = the penalty in force there) up to and including iteration
+        ``max_it``: iterations of the reference's loop (admm_solver_v3.py:655-733) with its own numbering, so that the rho
+        adaptation (``it < it_rho_limit``) sees the same counter as an uninterrupted run.  Returns (it, status, rho, trace rows)."""
+        ap = _Admm(rho, tau, tau, nu, it_rho_limit, eps_abs, eps_rel, max_it)
+        rows = max(max_it - it_start + 1, 1)
+        trace = np.zeros((rows, 6)); status = C.c_int(0); rho_out = C.c_double(rho)
+        it = lib().oracle_admm_run_from(C.byref(self.G), C.byref(ap), C.byref(self.inner), _p(self.zedge), _p(self.mu),
+                                        _p(self.copy), _p(self.xv), _p(self.zv), _p(self.yv), _p(trace), C.byref(status),
+                                        C.byref(self.ipm_iters), nthreads, int(it_start), C.byref(rho_out))
+        return it, status.value, rho_out.value, trace[:max(min(it, max_it) - it_start + 1, 0)]
+
+    _STATE = ("zedge", "mu", "copy", "xv", "zv", "yv")
+
+    def snapshot(self):
+        """copy of everything a continued run depends on: the ADMM state and the warm-start records of the vertex solves"""
+        snap = {k: getattr(self, k).copy() for k in self._STATE}
+        if getattr(self, "_warm", None) is not None:
+            snap["_warm"] = self._warm.copy()
+        return snap
+
+    def restore(self, snap):
+        for k, v in snap.items():
+            getattr(self, k)[...] = v      # in place: the C side holds pointers into these arrays
+
     def cost(self):
         return lib().oracle_compute_cost(C.byref(self.G), _p(self.zv), _p(self.zedge), C.c_double(self.inner.eps_edge))
 

@@ -125,29 +125,42 @@ def test_lattice_100k_eight_partitions_match_single(torch_gpu, lattice_100k):
 
 
 def test_lattice_r6_50k(torch_gpu, oracle_lib):
-    """BASELINE config 5 at full size (223 x 224 boxes in R^6, f32 state): the workgroup program; a few iterations with the
-    state properties, and the five sums of the first iteration against the oracle."""
+    """BASELINE config 5 at full size (223 x 224 boxes in R^6, f32 state): the workgroup program, BOX instantiation.  24 iterations:
+    the state properties on every one (20 of them with warm-started solves at full size), no inner failure, and the residual trace
+    of the first four -- one cold and three warm iterations -- against the oracle at 1e-6 relative (the oracle takes ~2 s per
+    iteration here)."""
     torch = torch_gpu
     g = lattice_boxes(223, 224, n=6, seed=0)
     assert g.num_vertices == 49954 and g.n == 6
     d = _solver(g, "f32")
     q = d.query()
     assert q["num_workgroup_vertices"] == g.num_vertices - 2 and q["num_waves"] == 0
-    d.reset(max_it=20)
+    n_it, n_cmp = 24, 4
+    d.reset(max_it=n_it + 5)
     first = None
-    for it in range(3):
+    iters = []
+    for it in range(n_it):
         d.vertex_step()
         sums = d.edge_step().clone()
         _check_state_properties(torch, g, d, sums, "f32")
         if it == 0:
             first = sums.cpu().numpy()
         d.control()
-    cb = d.read_control()
-    assert cb.it == 4 and cb.status == -1 and cb.inner_failures == 0
+        cb = d.read_control()
+        assert cb.inner_failures == 0 and cb.status == -1, (it, cb.inner_failures, cb.status)
+        iters.append(cb.inner_iters / (g.num_vertices - 2))
+    assert cb.it == n_it + 1
+    assert iters[-1] < 0.6 * iters[0], iters          # the later solves really restart from their records (about 3 against 9 iterations)
+    tr = d.trace[:n_cmp].cpu().numpy()
     o = oracle_lib.Oracle(g, ipm_tol=1e-9)
-    assert o.vertex_step(1.0, 1.0, nthreads=16) == 0
-    ref = o.edge_step(1.0)
-    assert np.allclose(first, ref, rtol=1e-4, atol=1e-8)      # f32 storage of the state
+    ora = o.run(max_it=n_cmp, eps_abs=0.0, eps_rel=0.0, nthreads=16)
+    assert ora["inner_failures"] == 0
+    # f32 storage of the state: the residuals of a 50k-vertex lattice agree to ~1e-6 relative (the S10k / S100k bound)
+    assert np.allclose(tr[:, 1], ora["trace"][:n_cmp, 1], rtol=2e-6, atol=1e-9), (tr[:, 1], ora["trace"][:n_cmp, 1])
+    assert np.allclose(tr[:, 2], ora["trace"][:n_cmp, 2], rtol=2e-6, atol=1e-9), (tr[:, 2], ora["trace"][:n_cmp, 2])
+    o1 = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    assert o1.vertex_step(1.0, 1.0, nthreads=16) == 0
+    assert np.allclose(first, o1.edge_step(1.0), rtol=1e-4, atol=1e-8)
 
 
 def test_benchmark4_tol_1e6_against_oracle(torch_gpu, oracle_lib):
@@ -197,11 +210,12 @@ def test_inner_failure_keeps_previous_copy(torch_gpu):
         assert cb.inner_failures >= n_generic - 4 and cb.status == -1
         assert torch.isfinite(d.copy).all() and torch.isfinite(d.zedge).all() and torch.isfinite(d.mu).all()
         deg = np.diff(g.inc_ptr)
-        for v in range(2, g.num_vertices):
-            if deg[v] >= 2:
-                sl = slice(int(g.inc_ptr[v]), int(g.inc_ptr[v + 1]))
-                assert d.copy[:, sl].abs().max().item() == 0.0 and d.yv[v].item() == 0.0
-                break
+        din = np.array([int((g.inc_out[g.inc_ptr[v]:g.inc_ptr[v + 1]] == 0).sum()) for v in range(g.num_vertices)])
+        generic = [v for v in range(g.num_vertices) if v not in (g.src, g.dst) and din[v] > 0 and deg[v] - din[v] > 0]
+        # EVERY generic vertex is looked at: a vertex whose solve failed in all three steps still holds the zeros it started with
+        kept = [v for v in generic
+                if d.copy[:, int(g.inc_ptr[v]):int(g.inc_ptr[v + 1])].abs().max().item() == 0.0 and d.yv[v].item() == 0.0]
+        assert len(kept) >= cb.inner_failures - 0 and len(kept) >= len(generic) - 4, (len(kept), len(generic), cb.inner_failures)
 
 
 def test_terminal_with_extent_is_refused(torch_gpu):
