@@ -998,7 +998,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         {   // stop on the barrier parameter alone (oracle/gcs_oracle.c); a vanishing step = precision exhausted
             const bool conv = !first_warm && (mu <= a.ipm_tol || (stalled && mu <= 1e3 * a.ipm_tol));
             bool stop = conv;
-            status = conv ? 0 : -1;
+            // (a WARM solve does not leave through the precision-exhausted rule: it is repeated cold -- oracle/gcs_oracle.c)
+            status = conv ? ((use_warm && !(mu <= a.ipm_tol)) ? -7 : 0) : -1;
             if (!(mu > 0.0)) { stop = true; status = -3; }
             if (!stop && it >= a.ipm_max_iter) { stop = true; status = -1; }
             if (stop) { if (status == 0) break; WG_FAIL_OR_RESTART(); }
@@ -1128,7 +1129,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_SYNC();
         WG_STAMP(2);
         if (wg_uniform(SC[SC_CONEFAIL]) != 0.0) {
-            status = mu <= 1e3 * a.ipm_tol ? 0 : -4;
+            status = (mu <= 1e3 * a.ipm_tol && !use_warm) ? 0 : -4;
             if (status == 0) break;
             WG_FAIL_OR_RESTART();
         }

@@ -717,12 +717,18 @@ restart:
                 w[W_BT + 2 * n] = B->Ty;
             }
         }
-        if (!first_warm && (mu <= ip->ipm_tol || (stalled && mu <= 1e3 * ip->ipm_tol))) { status = 0; break; }
+        if (!first_warm && (mu <= ip->ipm_tol || (stalled && mu <= 1e3 * ip->ipm_tol))) {
+            /* a WARM solve does not leave through the precision-exhausted rule: its start was off-centre (an iterate jammed against a
+             * bound makes steps of 1e-6 and is several 1e-3 off in that vertex's words); it counts as a failed warm attempt and is
+             * repeated cold below.  Cold solves keep the rule (on the fixtures it fires at mu <= 5e-9 only). */
+            status = (use_warm && !(mu <= ip->ipm_tol)) ? -7 : 0;
+            break;
+        }
         if (it == ip->ipm_max_iter) break;
 
         /* ---- scalings, block Hessians, border Hessian ---- */
         double wb[MAXN + 1], eta;
-        if (soc_scaling(q, P.ssoc, P.lsoc, F.Wsoc, F.Wsoci, wb, &eta)) { status = mu <= 1e3 * ip->ipm_tol ? 0 : -4; break; }
+        if (soc_scaling(q, P.ssoc, P.lsoc, F.Wsoc, F.Wsoci, wb, &eta)) { status = (mu <= 1e3 * ip->ipm_tol && !use_warm) ? 0 : -4; break; }
         const int ldq = MAXN + 1;
         double W2[(MAXN + 1) * (MAXN + 1)]; /* W^{-2} */
         for (int i = 0; i < q; ++i)

@@ -31,7 +31,7 @@ def _solver(g, dtype="f64", **kw):
     return DeviceSolver(g, dtype, device=0, **kw)
 
 
-def _check_state_properties(torch, g, d, sums, dtype):
+def _check_state_properties(torch, g, d, sums, dtype, it=0):
     """the five norms recomputed from the state, mu-pair invariant, activations in [0, 1], terminals on"""
     n = g.n
     tail = torch.from_numpy(g.edge_inc_tail.astype(np.int64)).cuda()
@@ -45,7 +45,8 @@ def _check_state_properties(torch, g, d, sums, dtype):
     assert torch.allclose(sums[4], (mu * mu).sum(), rtol=1e-9)
     # the two duals of a coupled word cancel: exactly in f64 arithmetic up to round-off, to storage precision (a few f32
     # ulps of the largest dual: the 100k lattice has coordinates ~300) with f32 state
-    pair_tol = 1e-12 if dtype == "f64" else 5e-7 * max(1.0, mu.abs().max().item())
+    # (f32: each dual update rounds both duals of a pair to storage independently, so the pair sum drifts by about an ulp per iteration)
+    pair_tol = 1e-12 if dtype == "f64" else 1.2e-7 * (it + 4) * max(1.0, mu.abs().max().item())
     assert (mu[:, tail] + mu[:, head]).abs().max().item() <= pair_tol
     assert z[2 * n].min().item() >= -1e-6 and z[2 * n].max().item() <= 1 + 1e-6
     assert d.yv[g.src].item() == 1.0 and d.yv[g.dst].item() == 1.0
@@ -70,7 +71,7 @@ def test_lattice_100k_single_handle(torch_gpu, oracle_lib, lattice_100k, dtype):
     for it in range(iters):
         d.vertex_step()
         sums = d.edge_step().clone()
-        _check_state_properties(torch, g, d, sums, dtype)
+        _check_state_properties(torch, g, d, sums, dtype, it)
         d.control()
     cb = d.read_control()
     assert cb.it == iters + 1 and cb.status == -1 and cb.inner_failures == 0
@@ -142,7 +143,7 @@ def test_lattice_r6_50k(torch_gpu, oracle_lib):
     for it in range(n_it):
         d.vertex_step()
         sums = d.edge_step().clone()
-        _check_state_properties(torch, g, d, sums, "f32")
+        _check_state_properties(torch, g, d, sums, "f32", it)
         if it == 0:
             first = sums.cpu().numpy()
         d.control()
