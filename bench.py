@@ -32,6 +32,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from gcs_admm_amd import IPM_TOL  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 F64_VECTOR_PEAK_TF = 78.6      # MI355X f64 vector peak (spec)
@@ -119,7 +120,7 @@ def cpu_baseline(g, workload, first, warmup, steps, seconds=20.0, dev=None, to_s
     import numpy as np
     from oracle.oracle import Oracle
     ncpu = os.cpu_count() or 1
-    o = Oracle(g, ipm_tol=1e-9)
+    o = Oracle(g, ipm_tol=IPM_TOL)
     transplant = dev is not None
     rho = 1.0
     if transplant:      # GPU state after `first` iterations -> oracle layout (incidence-major f64, pending mu rescale applied)
@@ -176,7 +177,7 @@ def cpu_baseline(g, workload, first, warmup, steps, seconds=20.0, dev=None, to_s
     if to_stop:
         runs = []
         for _ in range(3):
-            oo = Oracle(g, ipm_tol=1e-9)
+            oo = Oracle(g, ipm_tol=IPM_TOL)
             t0 = time.perf_counter()
             r = oo.run(nthreads=cores)
             runs.append((time.perf_counter() - t0, r["iterations"]))
@@ -551,7 +552,7 @@ def main(argv=None):
            "dtype": "f64" if dtype == "f64" else "f64 (interior point) on f32 state",
            "data": "synthetic" if args.workload != "benchmark4" else "fixture of the reference's test_data/benchmark4.py",
            "config": {"workload": args.workload, "V": g.num_vertices, "E": g.num_edges, "n": g.n,
-                      "state_dtype": dtype, "state_columns": columns, "inner_arithmetic": "f64", "ipm_tol": 1e-9, "vertex_program": program,
+                      "state_dtype": dtype, "state_columns": columns, "inner_arithmetic": "f64", "ipm_tol": IPM_TOL, "vertex_program": program,
                       "vertex_solves": "cold start every iteration" if args.cold_start else "warm start from the previous iteration's record (csrc/warm_start.h)",
                       "window": {"first_iteration": first + args.warmup + 1, "last_iteration": first + args.warmup + args.steps,
                                  "placement": ("centred on the run to the reference's stop (465 iterations)" if args.workload == "benchmark4" and args.first < 0
@@ -652,7 +653,7 @@ def main_sharded(args, rank, world, local):
             out["ms_per_step"] = block["ms_per_iteration"]
             out["rccl_ranks"] = block["rccl_ranks"]
             out["config"] = {"workload": "s100k", "V": block["V"], "E": block["E"], "n": 2, "state_dtype": "f32", "state_columns": "edge",
-                             "inner_arithmetic": "f64", "ipm_tol": 1e-9, "vertex_program": "wavefront",
+                             "inner_arithmetic": "f64", "ipm_tol": IPM_TOL, "vertex_program": "wavefront",
                              "window": block["window"], "parallelism": f"vertex partition: {world} row strips, one per GPU; RCCL halo exchange "
                                                                        "+ all-reduce of 6 f64 per iteration (gcsadmm_run_partitioned)", "seed": 0}
             out["value_1gpu_same_workload"] = block.get("single_gpu_iterations_per_sec")

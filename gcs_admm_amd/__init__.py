@@ -4,5 +4,12 @@ from .graph import (GcsGraph, build_graph, convert_pt_to_polytope, delta, graph_
                     lattice_boxes, polytopes_overlap)
 from .cases import load_fixture  # noqa: F401
 
+# Barrier parameter at which a vertex solve stops (gcsadmm_params.ipm_tol).  MOSEK's default relative gap behind the reference's
+# SolveInParallel (admm_solver_v3.py:490) is ~1e-8.  Swept on the oracle in round 4 (profiles/r04/README.md): 1e-9, 3e-9 and 5e-9 keep
+# every gate -- stop iterations 39 / 100 / 508 / 465 of the reference's records and 959 on the 10k lattice exact, every entry of the
+# reference's residual traces inside 2e-4 + 1e-3 |g|, the eps = 1e-6 run of benchmark4 converging to the monolithic optimum -- while
+# 1e-8 loses two of them (the 10k lattice stops at 958, the eps = 1e-6 run no longer converges).  3e-9: 8 % fewer Newton iterations.
+IPM_TOL = 3e-9
+
 __all__ = ["GcsGraph", "build_graph", "convert_pt_to_polytope", "delta", "graph_from_sets", "lattice_boxes",
-           "polytopes_overlap", "load_fixture"]
+           "polytopes_overlap", "load_fixture", "IPM_TOL"]

@@ -215,9 +215,11 @@ class DeviceSolver:
 
     # ------------------------------------------------------------------
     def reset(self, rho=1.0, tau_incr=2.0, tau_decr=2.0, nu=10.0, it_rho_limit=100, max_it=1000, eps_abs=1e-4,
-              eps_rel=1e-3, eps_edge=1e-4, ipm_tol=1e-9, ipm_max_iter=60, zero_state=True, cold_start=False):
+              eps_rel=1e-3, eps_edge=1e-4, ipm_tol=None, ipm_max_iter=60, zero_state=True, cold_start=False):
         """Start a loop with the reference's literals as defaults (admm_solver_v3.py:621-651).  ``cold_start``: every vertex
         solve starts from the fixed interior point instead of the record its previous solve left (csrc/warm_start.h)."""
+        if ipm_tol is None:
+            from . import IPM_TOL as ipm_tol      # the package default (gcs_admm_amd/__init__.py)
         self.params = Params(rho, tau_incr, tau_decr, nu, it_rho_limit, max_it, eps_abs, eps_rel, eps_edge,
                              ipm_tol, ipm_max_iter, 1 if cold_start else 0)
         if zero_state:

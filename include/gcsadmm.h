@@ -107,7 +107,7 @@ typedef struct gcsadmm_params {
     double eps_abs;      /* 1e-4                                     :647 */
     double eps_rel;      /* 1e-3                                     :648 */
     double eps_edge;     /* 1e-4 edge activation penalty             :388 */
-    double ipm_tol;      /* barrier parameter at which a vertex solve stops (1e-9) */
+    double ipm_tol;      /* barrier parameter at which a vertex solve stops (3e-9: the host default, gcs_admm_amd.IPM_TOL) */
     int32_t ipm_max_iter;/* 60 */
     int32_t cold_start;  /* 0 (default): a vertex solve restarts from the record its previous solve left in the handle's workspace
                             (csrc/warm_start.h; MOSEK at admm_solver_v3.py:490 starts cold -- the minimiser is the same);

@@ -1,5 +1,6 @@
 """CPU stand-in for DeviceSolver in the multi-rank tests: the oracle as the per-rank compute object
 behind the same interface (copy tensor, vertex_step, edge_step, control, read_control).  Tests only."""
+from gcs_admm_amd import IPM_TOL
 import types
 
 import numpy as np
@@ -11,10 +12,10 @@ from oracle import oracle as O
 class OracleBackend:
     def __init__(self, part=None, graph=None, **params):
         if part is not None:
-            self.o = O.Oracle(part.graph, ipm_tol=1e-9, num_incidences=part.num_incidences, inc_counted=part.inc_counted,
+            self.o = O.Oracle(part.graph, ipm_tol=IPM_TOL, num_incidences=part.num_incidences, inc_counted=part.inc_counted,
                               edge_counted=part.edge_counted, nx_global=part.nx_global, nmu_global=part.nmu_global)
         else:
-            self.o = O.Oracle(graph, ipm_tol=1e-9)
+            self.o = O.Oracle(graph, ipm_tol=IPM_TOL)
         self.copy = torch.from_numpy(self.o.copy)          # shares memory with the oracle's array
         self.ap = O.admm_params(**params)
         self.state = np.array([self.ap.rho, 1.0, 1.0, -1.0])

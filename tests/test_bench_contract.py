@@ -1,6 +1,7 @@
 """The driver's contract for bench.py, checked on bench.py itself: `--gpus N` really starts N ranks (CPU, gloo), the like-for-like CPU
 column times the window it says it times (tiny fixture, CPU), `check_line` -- the assertions bench.py runs on its own line before
 printing -- holds on the committed lines of the last profile run, and (GPU) on a line produced live."""
+from gcs_admm_amd import IPM_TOL
 import glob
 import json
 import os
@@ -56,8 +57,8 @@ def test_cpu_baseline_times_the_window_it_names(oracle_lib):
     assert c["window"] == {"first_iteration": first + warmup + 1, "last_iteration": first + warmup + steps}
     assert c["value"] > 0 and c["repetitions"] >= 1 and c["kind"] == "port" and c["cores"] >= 1 and str(c["cores"]) in c["thread_sweep"]
     # oracle_admm_run_from continues a run exactly
-    a = Oracle(g, ipm_tol=1e-9); ra = a.run(max_it=first + warmup + steps, eps_abs=0.0, eps_rel=0.0)
-    b = Oracle(g, ipm_tol=1e-9)
+    a = Oracle(g, ipm_tol=IPM_TOL); ra = a.run(max_it=first + warmup + steps, eps_abs=0.0, eps_rel=0.0)
+    b = Oracle(g, ipm_tol=IPM_TOL)
     _, _, rho, t1 = b.run_from(1, first + warmup, eps_abs=0.0, eps_rel=0.0)
     snap = b.snapshot()
     it, _, _, t2 = b.run_from(first + warmup + 1, first + warmup + steps, rho=rho, eps_abs=0.0, eps_rel=0.0)

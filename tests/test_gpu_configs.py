@@ -10,6 +10,7 @@ Where the oracle can afford the size it is run beside the device (same inner sol
 is checked through properties that need no second implementation: the five norms recomputed with torch from the state
 the kernels left behind, the mu-pair invariant, activations in [0, 1], s / t switched on, no inner failure.
 Reference loop: admm_solver_v3.py:655-733."""
+from gcs_admm_amd import IPM_TOL
 import numpy as np
 import pytest
 
@@ -76,7 +77,7 @@ def test_lattice_100k_single_handle(torch_gpu, oracle_lib, lattice_100k, dtype):
     cb = d.read_control()
     assert cb.it == iters + 1 and cb.status == -1 and cb.inner_failures == 0
     if dtype == "f64":
-        ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=iters, eps_abs=0.0, eps_rel=0.0, nthreads=16)
+        ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(max_it=iters, eps_abs=0.0, eps_rel=0.0, nthreads=16)
         tr = d.trace[:iters].cpu().numpy()
         assert ora["inner_failures"] == 0
         for col, key in ((1, "pri_res_seq"), (2, "dual_res_seq")):
@@ -153,13 +154,13 @@ def test_lattice_r6_50k(torch_gpu, oracle_lib):
     assert cb.it == n_it + 1
     assert iters[-1] < 0.6 * iters[0], iters          # the later solves really restart from their records (about 3 against 9 iterations)
     tr = d.trace[:n_cmp].cpu().numpy()
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     ora = o.run(max_it=n_cmp, eps_abs=0.0, eps_rel=0.0, nthreads=16)
     assert ora["inner_failures"] == 0
     # f32 storage of the state: the residuals of a 50k-vertex lattice agree to ~1e-6 relative (the S10k / S100k bound)
     assert np.allclose(tr[:, 1], ora["trace"][:n_cmp, 1], rtol=2e-6, atol=1e-9), (tr[:, 1], ora["trace"][:n_cmp, 1])
     assert np.allclose(tr[:, 2], ora["trace"][:n_cmp, 2], rtol=2e-6, atol=1e-9), (tr[:, 2], ora["trace"][:n_cmp, 2])
-    o1 = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o1 = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     assert o1.vertex_step(1.0, 1.0, nthreads=16) == 0
     assert np.allclose(first, o1.edge_step(1.0), rtol=1e-4, atol=1e-8)
 
@@ -172,7 +173,7 @@ def test_benchmark4_tol_1e6_against_oracle(torch_gpu, oracle_lib):
     classic = case["golden_classic"]["cost"]
     d = _solver(g)
     res = d.solve(chunk=500, max_it=40000, eps_abs=1e-6, eps_rel=1e-6)
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=40000, eps_abs=1e-6, eps_rel=1e-6, nthreads=16)
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(max_it=40000, eps_abs=1e-6, eps_rel=1e-6, nthreads=16)
     assert res["status"] == "converged" and ora["status"] == 0 and res["inner_failures"] == 0
     assert abs(res["iterations"] - ora["iterations"]) <= 0.01 * ora["iterations"], (res["iterations"], ora["iterations"])
     assert abs(res["cost"] - classic) <= 2.5e-4 * classic
@@ -185,7 +186,7 @@ def test_lattice_10k_f32_runs_to_the_same_stop(torch_gpu, oracle_lib):
     g = lattice_boxes(100, 100, seed=0)
     r64 = _solver(g, "f64").solve(chunk=100)
     r32 = _solver(g, "f32").solve(chunk=100)
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(nthreads=16)
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(nthreads=16)
     assert r64["status"] == r32["status"] == "converged" and ora["status"] == 0
     assert r64["iterations"] == r32["iterations"] == ora["iterations"]
     assert r64["inner_failures"] == 0 and r32["inner_failures"] == 0

@@ -11,6 +11,7 @@ Stated tolerances (f64):
     that differ in operation order inherit that scale in the worst case.
   * whole runs: stop iteration identical; residual traces within |a-b| <= 2e-4 + 1e-3|b|; cost 2e-4 rel.
 """
+from gcs_admm_amd import IPM_TOL
 import numpy as np
 import pytest
 
@@ -49,7 +50,7 @@ def _generic_mask(g):
 def test_step_by_step_against_oracle(torch_gpu, oracle_lib, name, program):
     torch = torch_gpu
     case, g = load_fixture(name)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     d = _solver(g, program=program)
     d.reset()
     diffs = []
@@ -87,7 +88,7 @@ def test_full_run_against_oracle_and_reference_record(torch_gpu, oracle_lib, nam
     gold = case["golden_v3"]
     d = _solver(g, program=program)
     res = d.solve()
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run()
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run()
     assert res["status"] == "converged" and res["inner_failures"] == 0
     assert res["iterations"] == ora["iterations"] == gold["iterations"]
     for key in ("pri_res_seq", "dual_res_seq"):
@@ -106,7 +107,7 @@ def test_rho_adaptation_and_mu_rescale(torch_gpu, oracle_lib):
     case, g = load_fixture("benchmark1")
     d = _solver(g)
     res = d.solve(rho=64.0, max_it=130, eps_abs=1e-9, eps_rel=1e-9)
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(rho=64.0, max_it=130, eps_abs=1e-9, eps_rel=1e-9)
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(rho=64.0, max_it=130, eps_abs=1e-9, eps_rel=1e-9)
     assert res["status"] == "max_it" and res["iterations"] == ora["iterations"] == 131
     assert np.array_equal(res["rho_seq"], ora["rho_seq"]) and len(set(res["rho_seq"])) > 1
     assert np.all(np.abs(res["pri_res_seq"] - ora["pri_res_seq"]) <= 2e-4 + 1e-3 * np.abs(ora["pri_res_seq"]))
@@ -130,7 +131,7 @@ def test_lattice_10k_properties(torch_gpu, oracle_lib, dtype):
     assert g.num_vertices == 10002
     d = _solver(g, dtype)
     d.reset(max_it=40)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     n = g.n
     tail = torch.from_numpy(g.edge_inc_tail.astype(np.int64)).cuda()
     head = torch.from_numpy(g.edge_inc_head.astype(np.int64)).cuda()
@@ -224,7 +225,7 @@ def test_other_space_dimensions(torch_gpu, oracle_lib, n):
         g = graph_from_sets(*interval_chain(8))
     else:
         g = lattice_boxes(6, 5, n=n, seed=1)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     d = _solver(g)
     d.reset(max_it=50)
     worst = 0.0
@@ -239,7 +240,7 @@ def test_other_space_dimensions(torch_gpu, oracle_lib, n):
     assert worst <= 2e-3
     d2 = _solver(g)
     res = d2.solve(max_it=40, eps_abs=0.0, eps_rel=0.0)
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=40, eps_abs=0.0, eps_rel=0.0)
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(max_it=40, eps_abs=0.0, eps_rel=0.0)
     assert res["iterations"] == ora["iterations"] == 41 and res["inner_failures"] == 0
     assert np.all(np.abs(res["pri_res_seq"] - ora["pri_res_seq"]) <= 2e-4 + 1e-3 * np.abs(ora["pri_res_seq"]))
 
@@ -251,7 +252,7 @@ def test_lattice_10k_trace_against_oracle(torch_gpu, oracle_lib):
     g = lattice_boxes(100, 100, seed=0)
     d = _solver(g)
     res = d.solve(max_it=60, eps_abs=0.0, eps_rel=0.0)
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=60, eps_abs=0.0, eps_rel=0.0, nthreads=32)
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(max_it=60, eps_abs=0.0, eps_rel=0.0, nthreads=32)
     assert res["inner_failures"] == 0 and ora["inner_failures"] == 0
     for key in ("pri_res_seq", "dual_res_seq"):
         a, b = res[key][1:], ora[key][1:]
@@ -271,7 +272,7 @@ def test_high_degree_vertex_and_degree_limit(torch_gpu, oracle_lib):
     assert np.diff(g.inc_ptr).max() >= 40
     d = _solver(g, program="wavefront")
     res = d.solve(max_it=80, eps_abs=0.0, eps_rel=0.0)
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=80, eps_abs=0.0, eps_rel=0.0)
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(max_it=80, eps_abs=0.0, eps_rel=0.0)
     assert res["inner_failures"] == 0
     for key in ("pri_res_seq", "dual_res_seq"):
         assert np.all(np.abs(res[key] - ora[key]) <= 2e-4 + 1e-3 * np.abs(ora[key])), key
@@ -285,7 +286,7 @@ def test_high_degree_vertex_and_degree_limit(torch_gpu, oracle_lib):
         q = d2.query()
         assert q["num_workgroup_vertices"] >= 1 and (program != "wavefront" or q["num_waves"] >= 1)
         res = d2.solve(max_it=60, eps_abs=0.0, eps_rel=0.0)
-        ora = oracle_lib.Oracle(g2, ipm_tol=1e-9).run(max_it=60, eps_abs=0.0, eps_rel=0.0)
+        ora = oracle_lib.Oracle(g2, ipm_tol=IPM_TOL).run(max_it=60, eps_abs=0.0, eps_rel=0.0)
         assert res["inner_failures"] == 0
         for key in ("pri_res_seq", "dual_res_seq"):
             assert np.all(np.abs(res[key] - ora[key]) <= 2e-4 + 1e-3 * np.abs(ora[key])), key
@@ -301,7 +302,7 @@ def test_degenerate_graphs(torch_gpu, oracle_lib):
     g = graph_from_sets(As, bs, 2)
     assert g.num_edges == 0
     res = _solver(g).solve(max_it=30)
-    ora0 = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=30)
+    ora0 = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(max_it=30)
     # nmu = 0 makes eps_dual = 0 and the strict test `dual < eps_dual` (admm_solver_v3.py:712) can never pass
     assert res["status"] == "max_it" and res["iterations"] == ora0["iterations"] == 31 and res["cost"] == 0.0
     As[0], bs[0] = A, np.array([1.0, 1.0, 1.0, 1.0])          # holds s
@@ -309,7 +310,7 @@ def test_degenerate_graphs(torch_gpu, oracle_lib):
     g = graph_from_sets(As, bs, 2)
     d = _solver(g)
     res = d.solve(max_it=200)
-    ora = oracle_lib.Oracle(g, ipm_tol=1e-9).run(max_it=200)
+    ora = oracle_lib.Oracle(g, ipm_tol=IPM_TOL).run(max_it=200)
     assert res["iterations"] == ora["iterations"] and res["status"] in ("converged", "max_it")
     assert np.isfinite(res["pri_res_seq"]).all() and np.isfinite(d.copy.cpu().numpy()).all()
     assert np.all(np.abs(res["pri_res_seq"] - ora["pri_res_seq"]) <= 2e-4 + 1e-3 * np.abs(ora["pri_res_seq"]))
@@ -329,7 +330,7 @@ def test_packing_and_reduction_modes(torch_gpu, oracle_lib, knobs):
     torch = torch_gpu
     from gcs_admm_amd.solver import DeviceSolver
     g = lattice_boxes(14, 11, seed=7)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     kw = dict(program="wavefront"); kw.update(knobs)
     d = DeviceSolver(g, "f64", device=0, **kw)
     q = d.query()
@@ -356,7 +357,7 @@ def test_random_scenes_fuzz(torch_gpu, oracle_lib, seed):
     rng = np.random.default_rng(100 + seed)
     As, bs = polygon_scene(5 + seed % 3, seed=seed, m=3 + seed % 5)
     g = graph_from_sets(As, bs, 2)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     d = _solver(g)
     rho = float([0.25, 1.0, 4.0][seed % 3])
     d.reset(rho=rho)
@@ -369,11 +370,10 @@ def test_random_scenes_fuzz(torch_gpu, oracle_lib, seed):
         assert o.vertex_step(rho, 1.0) == 0
         diff = np.abs(d.copy.cpu().numpy() - o.copy)
         # same bar as the step-by-step fixture tests: both solvers stop at mu <= 1e-9, weakly determined
-        # components (flat directions of a sub-problem) differ by up to ~1e-5, the bulk by far less.  The worst single entry is
-        # looser here than on reachable states (2e-3): from a RANDOM state one solve in some thousands jams against the bound
-        # y_e <= 1 (steps of 1e-6 at mu ~ 1e-7) and is accepted by the precision-exhausted rule (rule 5) with
-        # an error of a few 1e-3 in that vertex's words -- seen once in these 48 steps (seed 2, one vertex; the oracle, whose
-        # round-off differs, does not jam there).  On the runs of the fixtures and lattices the rule fires at mu <= 5e-9 only.
-        assert diff.max() <= 6e-3 and np.median(diff) <= 1e-7 and np.quantile(diff, 0.99) <= 1e-4
+        # components (flat directions of a sub-problem) differ by up to ~1e-5, the bulk by far less; worst single entry 2e-3 as on
+        # reachable states.  (Round 3 had to allow 6e-3 here: from a RANDOM state one warm solve in some thousands jammed against the
+        # bound y_e <= 1 -- steps of 1e-6 at mu ~ 1e-7 -- and left through the precision-exhausted rule with an error of a few 1e-3.
+        # A warm solve no longer leaves through that rule: it is repeated cold)
+        assert diff.max() <= 2e-3 and np.median(diff) <= 1e-7 and np.quantile(diff, 0.99) <= 1e-4
         assert np.abs(d.yv.cpu().numpy()[gen] - o.yv[gen]).max() <= 5e-4
         o.edge_step(1.0)

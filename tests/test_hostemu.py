@@ -7,6 +7,7 @@ Tolerance: both sides run the same interior-point iteration to barrier parameter
 the sub-problem minimiser itself is resolved to ~1e-4 in weakly determined components; two
 implementations that differ in operation order agree to ~1e-8 typically and to that 1e-4 scale in
 the worst case."""
+from gcs_admm_amd import IPM_TOL
 import ctypes as C
 import os
 import subprocess
@@ -53,7 +54,7 @@ def emu_step(lib, g, zedge, mu, rho, mu_scale, fn="emu_vertex_step", warm=None):
     cnt = np.zeros(2, dtype=np.int32); gen = np.zeros(V, dtype=np.int32)
     r = getattr(lib, fn)(g.n, V, g.num_edges, NI, _p(g.inc_ptr), _p(g.inc_edge), _p(g.inc_out), _p(g.poly_ptr),
                             _p(g.poly_A), _p(g.poly_b), _p(g.interior), g.src, g.dst, _p(zedge), _p(mu),
-                            C.c_double(rho), C.c_double(mu_scale), C.c_double(1e-4), C.c_double(1e-9), 60,
+                            C.c_double(rho), C.c_double(mu_scale), C.c_double(1e-4), C.c_double(IPM_TOL), 60,
                             _p(copy), _p(xv), _p(zv), _p(yv), _p(cnt), _p(gen))
     assert r == 0
     return copy, xv, zv, yv, cnt, gen
@@ -62,7 +63,7 @@ def emu_step(lib, g, zedge, mu, rho, mu_scale, fn="emu_vertex_step", warm=None):
 @pytest.mark.parametrize("name,steps", [("benchmark1", 20), ("benchmark4", 25), ("test_autogen2", 15)])
 def test_emulated_wave_program_matches_oracle(emu, oracle_lib, name, steps):
     case, g = load_fixture(name)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     w = WarmRecords(g)          # both sides restart from their own records, by the same rule (warm_start.h)
     diffs = []
     for it in range(steps):
@@ -91,7 +92,7 @@ def test_fixed_facet_variant_equals_generic(emu, oracle_lib):
     row duals in registers, compile-time facet normals); on a lattice of boxes both must produce the same numbers."""
     from gcs_admm_amd.graph import lattice_boxes
     g = lattice_boxes(7, 6, seed=2)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     wa, wb = WarmRecords(g), WarmRecords(g)
     for it in range(12):
         z0, m0 = o.zedge.copy(), o.mu.copy()
@@ -110,7 +111,7 @@ def test_fixed_facet_variant_equals_generic(emu, oracle_lib):
 def test_emulated_wave_program_other_dimensions(emu, oracle_lib, n):
     from gcs_admm_amd.graph import lattice_boxes
     g = lattice_boxes(5, 4, n=n, seed=1)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     w = WarmRecords(g)
     for it in range(6):
         copy, xv, zv, yv, cnt, gen = emu_step(emu, g, o.zedge.copy(), o.mu.copy(), 1.0, 1.0, warm=w)
@@ -128,7 +129,7 @@ def test_emulated_wave_program_high_degree(emu, oracle_lib):
     As, bs, n = star_case(24)
     g = graph_from_sets(As, bs, n)
     assert np.diff(g.inc_ptr).max() >= 40
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     w = WarmRecords(g)
     for it in range(10):
         copy, xv, zv, yv, cnt, gen = emu_step(emu, g, o.zedge.copy(), o.mu.copy(), 1.0, 1.0, warm=w)
@@ -186,7 +187,7 @@ def test_failed_warm_solve_is_repeated_cold_in_the_same_step(emu, oracle_lib):
     """a record the solve cannot continue from (its row duals made negative: the first complementarity test fails) costs a cold
     solve inside the same step, for that vertex alone, not an inner failure; the other vertices of the wavefront go on warm"""
     g = load_fixture("benchmark1")[1]
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9, warm_start=False)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL, warm_start=False)
     w = WarmRecords(g)
     for _ in range(3):
         emu_step(emu, g, o.zedge, o.mu, 1.0, 1.0, warm=w)

@@ -4,6 +4,7 @@ independent.  Checked here without a GPU: (1) the algorithm against the CPU orac
 general polygons and boxes; (2) task-order independence: ascending and descending task order agree to round-off (the only
 order-dependent operations are the floating-point sums of the workgroup reductions); (3) no read of unwritten LDS
 (the emulation poisons it with NaN).  The GPU parity tests proper are test_gpu_parity.py / test_gpu_configs.py."""
+from gcs_admm_amd import IPM_TOL
 import ctypes as C
 import os
 import subprocess
@@ -56,7 +57,7 @@ def wg_step(lib, fn, g, zedge, mu, rho=1.0, mu_scale=1.0, max_iter=60, warm=None
     st = np.zeros(V, dtype=np.int32); it = np.zeros(V, dtype=np.int32)
     r = getattr(lib, fn)(g.n, V, g.num_edges, NI, _p(g.inc_ptr), _p(g.inc_edge), _p(g.inc_out), _p(g.poly_ptr), _p(g.poly_A),
                          _p(g.poly_b), _p(g.interior), g.src, g.dst, _p(zedge), _p(mu), C.c_double(rho), C.c_double(mu_scale),
-                         C.c_double(1e-4), C.c_double(1e-9), max_iter, _p(copy), _p(xv), _p(zv), _p(yv), _p(cnt), _p(gen),
+                         C.c_double(1e-4), C.c_double(IPM_TOL), max_iter, _p(copy), _p(xv), _p(zv), _p(yv), _p(cnt), _p(gen),
                          _p(st), _p(it))
     assert r == 0
     return copy, xv, zv, yv, cnt, gen == 1, st, it
@@ -77,7 +78,7 @@ def test_workgroup_program_matches_oracle_and_is_order_independent(libs, oracle_
         g = graph_from_sets(*interval_chain(6))
     else:
         g = lattice_boxes(lat[0], lat[1], n=lat[2], seed=1) if lat else load_fixture(name)[1]
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     wa, wb = WarmRecords(fwd, g), WarmRecords(fwd, g)       # oracle and both builds restart from their own records (same rule)
     diffs = []
     for it in range(steps):
@@ -115,7 +116,7 @@ def test_box_instantiation_equals_generic(libs, oracle_lib, lat):
     independence of the BOX regions (ascending / descending)"""
     fwd, rev = libs
     g = lattice_boxes(lat[0], lat[1], n=lat[2], seed=1)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     wa, wb, wc = (WarmRecords(fwd, g) for _ in range(3))      # every build restarts from its own records (warm_start.h)
     for it in range(5):
         z0, m0 = o.zedge.copy(), o.mu.copy()
@@ -156,7 +157,7 @@ def test_failed_warm_solve_is_repeated_cold(libs, oracle_lib):
     solve in the same call, not an inner failure; the result is the cold solve's"""
     fwd, _ = libs
     g = load_fixture("benchmark1")[1]
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9, warm_start=False)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL, warm_start=False)
     w = WarmRecords(fwd, g)
     for _ in range(3):
         wg_step(fwd, "wg_emu_vertex_step", g, o.zedge, o.mu, warm=w)

@@ -3,6 +3,7 @@ path lengths of benchmark1-4 (3.236065 / 7.413745 / 60.177021 / 32.627198, recom
 y_v_rounded of the v3 records).  The relaxed activations fed in come from the CPU oracle's run, so this
 test needs no GPU.  Path *sets* are not compared: ties exist (benchmark3's record passes through a region
 the equally short most-probable path skips)."""
+from gcs_admm_amd import IPM_TOL
 import numpy as np
 import pytest
 
@@ -15,7 +16,7 @@ from gcs_admm_amd.rounding import rounding, solve_path_restriction
 def test_rounded_length_matches_reference_record(oracle_lib, name):
     case, g = load_fixture(name)
     As, bs, n, _, _ = fixture_sets(name)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     o.run(nthreads=4)
     V, E = g.keys, g.edges_as_keys()
     y_e = {e: float(o.zedge[2 * n, i]) for i, e in enumerate(E)}

@@ -1,6 +1,7 @@
 """Graph construction at scale: the oracle's LP decisions against the committed
 edge lists (CPU), the sort-and-sweep broad phase against brute force (CPU), and the device LPs
 (csrc/polytope_lp.hip through the C ABI) against the oracle and the fixtures (GPU)."""
+from gcs_admm_amd import IPM_TOL
 import os
 import sys
 
@@ -222,7 +223,7 @@ def test_device_scene_far_from_origin_end_to_end(oracle_lib):
     assert [list(e) for e in PO.edges(As, bs)] == [[g.keys[t], g.keys[h]] for t, h in zip(g.edge_tail, g.edge_head)]
     _, rad, st = PolytopeScene([(As[k], bs[k]) for k in As]).centers()
     assert np.all(st == 0) and np.all(rad > 0)
-    o = oracle_lib.Oracle(g, ipm_tol=1e-9)
+    o = oracle_lib.Oracle(g, ipm_tol=IPM_TOL)
     d = DeviceSolver(g, "f64", device=0)
     d.reset()
     for it in range(10):

@@ -1,6 +1,7 @@
 """Diagnostic: long runs of the synthetic lattices -- inner failures, finiteness, trace vs the CPU oracle."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
+from gcs_admm_amd import IPM_TOL  # noqa: E402
 import numpy as np, torch
 from gcs_admm_amd.graph import lattice_boxes
 from gcs_admm_amd.solver import DeviceSolver
@@ -13,7 +14,7 @@ for dt in ("f64", "f32"):
           "wall %.2fs" % el, "pri/dual last", res["pri_res_seq"][-1], res["dual_res_seq"][-1], flush=True)
     if dt == "f64":
         ref = res
-o = Oracle(g, ipm_tol=1e-9)
+o = Oracle(g, ipm_tol=IPM_TOL)
 t0 = time.time(); r = o.run(max_it=120, eps_abs=0.0, eps_rel=0.0, nthreads=32); print("oracle 120 its %.1fs" % (time.time() - t0))
 k = 121
 print("max rel diff pri (f64 GPU vs oracle, 120 its): %.3e" % np.max(np.abs(ref["pri_res_seq"][:k] - r["pri_res_seq"][:k]) / (1e-6 + r["pri_res_seq"][:k])))

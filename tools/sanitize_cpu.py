@@ -3,6 +3,7 @@ import sys, ctypes as C, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from gcs_admm_amd import IPM_TOL  # noqa: E402
 from gcs_admm_amd.cases import load_fixture
 from gcs_admm_amd.graph import lattice_boxes, graph_from_sets
 from conftest import star_case
@@ -19,7 +20,7 @@ graphs=[('benchmark4',load_fixture('benchmark4')[1],'emu_vertex_step'),('benchma
         ('lattice m4',lattice_boxes(9,7,seed=1),'emu_vertex_step_m4'),('lattice n6',lattice_boxes(5,4,n=6,seed=1),'emu_vertex_step'),
         ('star',graph_from_sets(*star_case(24)),'emu_vertex_step')]
 for name,g,fn in graphs:
-    o=Oracle(g,ipm_tol=1e-9)
+    o=Oracle(g,ipm_tol=IPM_TOL)
     for it in range(6):
         step(fn,g,o.zedge.copy(),o.mu.copy()); o.vertex_step(1.0,1.0,1); o.edge_step(1.0)
     print(name,'ok')
@@ -37,7 +38,7 @@ def wg_step(g, z, m):
 wg_graphs = [('benchmark4', load_fixture('benchmark4')[1], 0), ('lattice n2', lattice_boxes(6, 5, seed=1), 0), ('lattice n3 box', lattice_boxes(4, 3, n=3, seed=1), 1),
              ('lattice n6', lattice_boxes(4, 3, n=6, seed=1), 0), ('lattice n6 box', lattice_boxes(4, 3, n=6, seed=1), 1), ('star', graph_from_sets(*star_case(24)), 0)]
 for name, g, box in wg_graphs:
-    o = Oracle(g, ipm_tol=1e-9)
+    o = Oracle(g, ipm_tol=IPM_TOL)
     wg.wg_emu_set_box(box)
     for it in range(4):
         wg_step(g, o.zedge.copy(), o.mu.copy()); o.vertex_step(1.0, 1.0, 1); o.edge_step(1.0)
@@ -50,5 +51,5 @@ O._lib=C.CDLL('/tmp/libo_asan.so'); O._lib.oracle_compute_cost.restype=C.c_doubl
 from gcs_admm_amd.cases import load_fixture
 from gcs_admm_amd.graph import lattice_boxes
 for name in ('benchmark1','benchmark4'):
-    case,g=load_fixture(name); r=O.Oracle(g,ipm_tol=1e-9).run(nthreads=2); print(name,r['iterations'])
-g=lattice_boxes(5,4,n=6,seed=1); r=O.Oracle(g,ipm_tol=1e-9).run(max_it=5,eps_abs=0,eps_rel=0,nthreads=2); print('n6',r['iterations'])
+    case,g=load_fixture(name); r=O.Oracle(g,ipm_tol=IPM_TOL).run(nthreads=2); print(name,r['iterations'])
+g=lattice_boxes(5,4,n=6,seed=1); r=O.Oracle(g,ipm_tol=IPM_TOL).run(max_it=5,eps_abs=0,eps_rel=0,nthreads=2); print('n6',r['iterations'])

@@ -4,6 +4,7 @@ import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gcs_admm_amd import IPM_TOL  # noqa: E402
 import torch
 from gcs_admm_amd.cases import load_fixture
 from gcs_admm_amd.graph import lattice_boxes, graph_from_sets
@@ -16,7 +17,7 @@ from oracle.oracle import Oracle
 out = {}
 
 def parity(name, g, program, steps=6, dtype="f64"):
-    o = Oracle(g, ipm_tol=1e-9)
+    o = Oracle(g, ipm_tol=IPM_TOL)
     d = DeviceSolver(g, dtype, device=0, program=program)
     d.reset()
     worst = 0.0
