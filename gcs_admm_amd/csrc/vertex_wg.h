@@ -44,6 +44,7 @@ using gcs_math::sqrt_nr;
 constexpr int WG_THREADS = GCS_WG_THREADS;        // threads per workgroup (a power of two, whole wavefronts)
 constexpr int WG_WAVES = WG_THREADS / 64;
 constexpr int WG_ITEM_WAVES = WG_WAVES > 1 ? WG_WAVES - 1 : 1;   // wavefronts that share the items of a wave-local pipeline
+constexpr int WG_KAPPA_TID = WG_WAVES > 1 ? (WG_WAVES - 1) * 64 - 1 : WG_THREADS - 1;   // WG_KAPPA's lane
 constexpr double CHOL_SKIP = 1e-12;
 constexpr double REG_DELTA = 1e-7;   // Tikhonov term on every centred unknown except t (oracle/gcs_oracle.c REG_DELTA)
 
@@ -65,6 +66,12 @@ __device__ __forceinline__ int wg_tid()
 #define WG_ONE() if (gcs_wg::wg_tid() == 0)
 // the serial cone algebra runs on the LAST thread: wave 3 has the fewest row / entry tasks in every region
 #define WG_CONE() if (gcs_wg::wg_tid() == gcs_wg::WG_THREADS - 1)
+// the cone's two step bounds (slack side, dual side) are the SAME code on different data: two lanes of the last wavefront, l = 0, 1, run
+// them side by side (one instruction stream) instead of one lane running them back to back
+#define WG_CONE2(l) for (int l = gcs_wg::wg_tid() - (gcs_wg::WG_THREADS - 2); l >= 0 && l < 2; l = 2)
+// a third serial piece of cone algebra that is independent of those two (the corrector's second-order term) runs meanwhile on the last
+// lane of the wavefront BEFORE the last one (that lane has no item of the wave-local pipeline: 63 lanes of items would be 12 units)
+#define WG_KAPPA() if (gcs_wg::wg_tid() == gcs_wg::WG_KAPPA_TID)
 // work that one WAVEFRONT does with a matrix row per lane (wave_ldl below): no barrier inside, broadcasts by readlane
 #define WG_WAVE0() if (gcs_wg::wg_tid() < 64)
 // `cnt` pieces of such work, piece w on wavefront w (one matrix per wavefront; a workgroup with fewer wavefronts takes them in turns)
@@ -98,6 +105,8 @@ __device__ __forceinline__ int wg_tid()
 #define WG_SYNC() do { } while (0)
 #define WG_ONE() if (true)
 #define WG_CONE() if (true)
+#define WG_CONE2(l) for (int l = 0; l < 2; ++l)
+#define WG_KAPPA() if (true)
 #define WG_WAVE0() if (true)
 #define WG_FIRST_WAVES(w, cnt) for (int w = 0; w < (cnt); ++w)
 #define WG_ITEM_FOR(q, i, count, PER) WG_FOR(t_, (count) * (PER)) if (const int q = t_ / (PER), i = t_ - q * (PER); true)
@@ -157,9 +166,9 @@ constexpr int pad2(int x) { return (x + 1) & ~1; }      // keep every array 16-b
 template <int N> struct WSoc {   // cone block
     static constexpr int Q = N + 1;
     static constexpr int SS = 0, LS = Q, WB = 2 * Q, LT = 3 * Q, CV = LT + Q, SU = CV + N, DSSA = SU + N * N, DLSA = DSSA + Q,
-                         DSS = DLSA + Q, DLS = DSS + Q, KS = DLS + Q, SIZE = KS + Q;
+                         DSS = DLSA + Q, DLS = DSS + Q, KS = DLS + Q, KQ = KS + Q, SIZE = KQ + Q;
 };
-enum { SC_T = 0, SC_DT, SC_DTA, SC_ALPHA, SC_CONEFAIL, SC_C0, SC_ETA, SC_GT, SC_AMAXC, SC_C1C, SC_C2C, SC_N = 12 };
+enum { SC_T = 0, SC_DT, SC_DTA, SC_ALPHA, SC_CONEFAIL, SC_C0, SC_ETA, SC_GT, SC_AMAXC, SC_C1C, SC_C2C, SC_AMAXC2, SC_IDET, SC_N = 14 };
 template <int N> struct WL {
     using D = WD<N>;
     static constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1;
@@ -345,7 +354,10 @@ GCS_HD constexpr int pki(int i, int j) { return i * (i + 1) / 2 + j; }   // pack
 // more than the readlanes it saves.)
 // Host build: the same column-by-column elimination written serially.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
+// With a right-hand side b (not null) the call also solves A x = b: the forward substitution rides in the elimination (one more
+// readlane + FMA per column, off the pivot chain), the backward substitution follows from the stored factor -- the affine solve of a
+// Newton iteration, whose right-hand side exists before the factorisation starts, costs half a wave_ldl_solve and no region of its own.
+template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd, const double *b = nullptr, double *x = nullptr)
 {
     static_assert(DIM <= 64, "one row per lane");
 #if WG_DEVICE
@@ -354,7 +366,7 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
 #pragma unroll
     for (int j = 0; j < DIM; ++j) a[j] = Mq[row * DIM + j];
     const double od = Mq[row * DIM + row];
-    double myr = 0.0;
+    double myr = 0.0, v = b ? b[row] : 0.0;
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
         double dk = lane_bcast(a[k], k);
@@ -365,11 +377,21 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
         if (lane == k) myr = rk;
 #pragma unroll
         for (int j = k + 1; j < DIM; ++j) a[j] -= l * lane_bcast(col, j);     // (entries right of the diagonal: unused values)
+        if (b) v -= (row > k ? l : 0.0) * lane_bcast(v, k);                   // y = L^{-1} b: lane k's entry is final at step k
     }
     if (lane < DIM) {
 #pragma unroll
         for (int j = 0; j < DIM - 1; ++j) Mq[lane * DIM + j] = a[j];
         rd[lane] = myr;
+    }
+    if (b) {      // x = L^{-T} D^{-1} y: column `row` of L from the factor just stored (LDS operations of one wavefront complete in order)
+        v *= myr;
+        double l[DIM];
+#pragma unroll
+        for (int k = 1; k < DIM; ++k) l[k] = k > row ? Mq[k * DIM + row] : 0.0;
+#pragma unroll
+        for (int k = DIM - 1; k >= 1; --k) v -= l[k] * lane_bcast(v, k);
+        if (lane < DIM) x[lane] = v;
     }
 #else
     double od[DIM], col[DIM];
@@ -385,6 +407,16 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
             Mq[i * DIM + k] = l;
             for (int j = k + 1; j <= i; ++j) Mq[i * DIM + j] -= l * col[j];
         }
+    }
+    if (b) {
+        double v[DIM];
+        for (int i = 0; i < DIM; ++i) v[i] = b[i];
+        for (int k = 0; k < DIM - 1; ++k)
+            for (int i = k + 1; i < DIM; ++i) v[i] -= Mq[i * DIM + k] * v[k];
+        for (int i = 0; i < DIM; ++i) v[i] *= rd[i];
+        for (int k = DIM - 1; k >= 1; --k)
+            for (int i = 0; i < k; ++i) v[i] -= Mq[k * DIM + i] * v[k];
+        for (int i = 0; i < DIM; ++i) x[i] = v[i];
     }
 #endif
 }
@@ -551,6 +583,9 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     using SO = WSoc<N>;
     using W = std::conditional_t<BOX, WLBox<N>, WL<N>>;       // LDS layout: dense K_e / X_e / B_e per unit, or their structured forms
     constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1, Q = D::Q, NS = D::NS, TA = D::TA;
+    constexpr bool FUSE_AFFINE = NB1 <= 13;      // the affine solve inside the border factorisation (wave_ldl with a right-hand side)
+    constexpr bool KAPPA_EARLY = N <= 3;         // the corrector's cone term formed beside the affine solve's tail (solve_tail); at n = 6 the
+                                                 // cone is not that region's critical path and the extra lane costs registers (BOX: 167 -> 169)
     const bool prox = a.prox_q != nullptr;       // border-only problem with a separable quadratic (no blocks, no sides)
     const int lo = a.inc_ptr[v], d = prox ? 0 : a.inc_ptr[v + 1] - lo, d_in = prox ? 0 : a.deg_in[v], d_out = d - d_in;
     const bool sides = d > 0;
@@ -687,28 +722,26 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
     };
     auto rhs_tasks = [&](Place &pl, bool wk) {     // right-hand side in the (x, u = z1 - z2, z2, y_v) variables, t eliminated
-        WG_FOR_AT(q, NB1, pl.at(NB1)) {
-            const double *u0 = UN(0);
-            auto base_z = [&](int i) { return -gval(u0, 0, i, wk) - sm[W::VV + i] - sm[W::VV + NW + i]; };
-            double r;
-            if (q < NX) {
-                r = -REG_DELTA * sm[W::XV + q] - sm[W::XBG + q] - sm[W::XBG + NX + q];
-                if (prox) r -= sm[W::PQ + q] * (sm[W::XV + q] + CEN[q < N ? q : q - N] - sm[W::PC + q]);
-                if (wk) r -= sm[W::SOL + q];       // sum over the units of G'kappa's x part (solve_head's first region put it there)
-                for (int s = 0; s < 2; ++s) {
-                    const double *BXs = sm + W::BXS + s * NW * NX;
+        // four KINDS of row, each on its own wavefront: as branches of one loop the nine rows sat in one wavefront, which ran the four
+        // bodies back to back (1 750 cycles for this region on benchmark4; the x rows alone are a 20-term sum)
+        const double *u0 = UN(0);
+        auto base_z = [&](int i) { return -gval(u0, 0, i, wk) - sm[W::VV + i] - sm[W::VV + NW + i]; };
+        WG_FOR_AT(q, NX, pl.at(NX)) {             // x rows
+            double r = -REG_DELTA * sm[W::XV + q] - sm[W::XBG + q] - sm[W::XBG + NX + q];
+            if (prox) r -= sm[W::PQ + q] * (sm[W::XV + q] + CEN[q < N ? q : q - N] - sm[W::PC + q]);
+            if (wk) r -= sm[W::SOL + q];       // sum over the units of G'kappa's x part (solve_head's first region put it there)
+            for (int s = 0; s < 2; ++s) {
+                const double *BXs = sm + W::BXS + s * NW * NX;
 #pragma unroll
-                    for (int i = 0; i < NW; ++i) r -= BXs[i * NX + q] * sm[W::VV + s * NW + i];
-                }
-            } else if (q < NX + N) {          // u rows: r_z1 + cv gt / c0
-                const int k = q - NX;
-                r = base_z(k) + SOC[SO::CV + k] * SC[SC_GT] * rcp(SC[SC_C0]);
-            } else if (q < NX + 2 * N) {      // z2 rows: r_z1 + r_z2 (the cone terms cancel)
-                const int k = q - NX - N;
-                r = base_z(k) + base_z(N + k);
-            } else r = base_z(2 * N);
+                for (int i = 0; i < NW; ++i) r -= BXs[i * NX + q] * sm[W::VV + s * NW + i];
+            }
             sm[W::RHS + q] = r;
         }
+        WG_FOR_AT(k, N, pl.at(N))                 // u rows: r_z1 + cv gt / c0
+            sm[W::RHS + NX + k] = base_z(k) + SOC[SO::CV + k] * SC[SC_GT] * rcp(SC[SC_C0]);
+        WG_FOR_AT(k, N, pl.at(N))                 // z2 rows: r_z1 + r_z2 (the cone terms cancel)
+            sm[W::RHS + NX + N + k] = base_z(k) + base_z(N + k);
+        WG_FOR_AT(k, 1, pl.at(1)) sm[W::RHS + NX + 2 * N + k] = base_z(2 * N);      // y_v row
     };
     auto solve_head = [&](bool wk) {
         {
@@ -735,39 +768,29 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_SYNC();
         WG_STAMP(33);
     };
-    // the cone's part of a direction, by the cone thread as soon as (d zeta, dt) exist (inside solve_tail, beside the d nu
-    // tasks): slack / dual directions of the cone, its step bound and (affine direction) its share of the mu_aff sums
-    auto cone_step = [&](int part, int dt_slot, bool wk) {
-        // three parts, one per region of solve_tail (d nu, r_e, d w_e: all short and independent of the cone)
-        const int oDS = wk ? SO::DSS : SO::DSSA, oDL = wk ? SO::DLS : SO::DLSA;
-        if (part == 0) {
-            const double *u0 = UN(0);
-            double wb[Q], xs[Q], ys[Q];
-            xs[0] = SC[dt_slot];
+    // the cone's part of a direction, as soon as (d zeta, dt) exist: slack direction xs = (dt, d z1 - d z2) and dual direction
+    // dl = kappa - lambda - W^{-2} xs (kappa = 0 for the affine direction)
+    auto cone_dir = [&](int dt_slot, bool wk, double (&xs)[Q], double (&dl)[Q]) {
+        const double *u0 = UN(0);
+        double wb[Q], ys[Q];
+        xs[0] = SC[dt_slot];
 #pragma unroll
-            for (int k = 0; k < N; ++k) xs[1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
+        for (int k = 0; k < N; ++k) xs[1 + k] = u0[W::DW + k] - u0[W::DW + N + k];
 #pragma unroll
-            for (int k = 0; k < Q; ++k) wb[k] = SOC[SO::WB + k];
-            soc_apply_W2<Q>(wb, SC[SC_ETA], xs, ys);
-            double c1c = 0, c2c = 0;
+        for (int k = 0; k < Q; ++k) wb[k] = SOC[SO::WB + k];
+        soc_apply_W2<Q>(wb, SC[SC_ETA], xs, ys);
 #pragma unroll
-            for (int k = 0; k < Q; ++k) {
-                const double dl = (wk ? SOC[SO::KS + k] : 0.0) - SOC[SO::LS + k] - ys[k];
-                SOC[oDS + k] = xs[k]; SOC[oDL + k] = dl;
-                c1c += SOC[SO::SS + k] * dl + SOC[SO::LS + k] * xs[k];
-                c2c += xs[k] * dl;
-            }
-            SC[SC_C1C] = c1c; SC[SC_C2C] = c2c;
-        } else if (part == 1) SC[SC_AMAXC] = gcs_math::soc_max_step<Q>(SOC + SO::SS, SOC + oDS);
-        else SC[SC_AMAXC] = fmin(SC[SC_AMAXC], gcs_math::soc_max_step<Q>(SOC + SO::LS, SOC + oDL));
+        for (int k = 0; k < Q; ++k) dl[k] = (wk ? SOC[SO::KS + k] : 0.0) - SOC[SO::LS + k] - ys[k];
     };
     // The tail of a solve.  (1) one wavefront: substitutions with the border factor; (2) w_s, dx, d zeta, dt spread over the
     // threads; (3) a wave-local pipeline: every item wavefront repeats the 2 NW values of d nu_s for itself, then runs
     // r_e -> d w_e for ITS units, while the cone thread (last wavefront) does the cone's three parts.  (Merging (1) and (2) into
     // the one wavefront was measured slower: 2 250 against 1 830 cycles.)
     auto solve_tail = [&](int dt_slot, bool wk) {
-        WG_WAVE0() wave_ldl_solve<NB1>(sm + W::M, sm + W::PIVM, sm + W::RHS, sm + W::SOL);
-        WG_SYNC();
+        if (wk || !FUSE_AFFINE) {      // (the affine solve's substitutions rode in the border factorisation: wave_ldl with a right-hand side)
+            WG_WAVE0() wave_ldl_solve<NB1>(sm + W::M, sm + W::PIVM, sm + W::RHS, sm + W::SOL);
+            WG_SYNC();
+        }
         WG_STAMP(34);
         // solution back in (x, z1, z2, y_v): dz1 = du + dz2
         auto dzeta = [&](int i) { return i < N ? sm[W::SOL + NX + i] + sm[W::SOL + NX + N + i] : sm[W::SOL + NX + i]; };
@@ -792,7 +815,57 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(36);
-        WG_CONE() { cone_step(0, dt_slot, wk); cone_step(1, dt_slot, wk); cone_step(2, dt_slot, wk); }
+        // the cone, beside the pipeline below.  Two lanes of the last wavefront form the cone's directions (both the same values) and
+        // then ONE step bound each, side by side: lane 0 the slack side, lane 1 the dual side (the two bounds back to back on one lane
+        // were this step's critical path: a square root and two reciprocal chains each).  A third lane, on another wavefront, forms
+        // what the corrector's kappa needs from the AFFINE cone directions -- everything but sigma mu -- so that the corrector's
+        // cone thread has three multiplications left (it was the critical path of the G'kappa region).
+        auto cone_bounds = [&](int l) {      // l = 0: the slack side's bound, 1: the dual side's, 2: both (one lane, back to back)
+            const int oDS = wk ? SO::DSS : SO::DSSA, oDL = wk ? SO::DLS : SO::DLSA;
+            double xs[Q], dl[Q], bs[Q], dr[Q];
+            cone_dir(dt_slot, wk, xs, dl);
+            double c1c = 0, c2c = 0;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                const double sk = SOC[SO::SS + k], lk = SOC[SO::LS + k];
+                SOC[oDS + k] = xs[k]; SOC[oDL + k] = dl[k];
+                c1c += sk * dl[k] + lk * xs[k];
+                c2c += xs[k] * dl[k];
+                bs[k] = l == 1 ? lk : sk; dr[k] = l == 1 ? dl[k] : xs[k];
+            }
+            SC[SC_C1C] = c1c; SC[SC_C2C] = c2c;
+            SC[l == 1 ? SC_AMAXC2 : SC_AMAXC] = gcs_math::soc_max_step<Q>(bs, dr);
+            if (l == 2) SC[SC_AMAXC2] = gcs_math::soc_max_step<Q>(SOC + SO::LS, dl);
+        };
+        if constexpr (KAPPA_EARLY) { WG_CONE2(l) cone_bounds(l); }
+        else { WG_CONE() cone_bounds(2); }
+        if constexpr (KAPPA_EARLY) WG_KAPPA() if (!wk) {      // W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) ) and 1 / det(s): kappa_soc = sigma mu s^{-1} - the former
+            double xs[Q], dl[Q], wb[Q], a1[Q], a2[Q], pr[Q], qv[Q], lt[Q];
+            cone_dir(dt_slot, false, xs, dl);
+            const double eta = SC[SC_ETA];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) { wb[k] = SOC[SO::WB + k]; lt[k] = SOC[SO::LT + k]; }
+            soc_apply_Wi<Q>(wb, eta, xs, a1);
+            soc_apply_W<Q>(wb, eta, dl, a2);
+            double dsum = 0;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) dsum += a1[k] * a2[k];
+            pr[0] = dsum;
+#pragma unroll
+            for (int k = 1; k < Q; ++k) pr[k] = a1[0] * a2[k] + a2[0] * a1[k];
+            const double det = gcs_math::soc_det<Q>(lt);
+            double ld1 = 0;
+#pragma unroll
+            for (int k = 1; k < Q; ++k) ld1 += lt[k] * pr[k];
+            qv[0] = (lt[0] * pr[0] - ld1) * rcp(det);
+            const double ilt0 = rcp(lt[0]);
+#pragma unroll
+            for (int k = 1; k < Q; ++k) qv[k] = (pr[k] - qv[0] * lt[k]) * ilt0;
+            soc_apply_Wi<Q>(wb, eta, qv, a1);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) SOC[SO::KQ + i] = a1[i];
+            SC[SC_IDET] = rcp(gcs_math::soc_det<Q>(SOC + SO::SS));
+        }
         WG_REPL_FOR(t, 2 * NW) {      // d nu_s = Bs^{-1} w_s
             const int s = t / NW, i = t - s * NW;
             const double *Bsi = sm + W::BSI + s * NW * NW;
@@ -1441,7 +1514,10 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         WG_SYNC();
         WG_STAMP(10);
-        WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM);      // L D L' inside one wavefront; no explicit inverse
+        // L D L' inside one wavefront; no explicit inverse; the affine solve (not in a re-centring iteration) in the same pass
+        // (up to n = 3: at n = 6 the 25 x 25 instance with the extra chain costs the BOX instantiation the registers of its third workgroup per CU)
+        if constexpr (FUSE_AFFINE) { WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM, first_warm ? nullptr : sm + W::RHS, sm + W::SOL); }
+        else { WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM); }
         WG_SYNC();
         WG_STAMP(11);
         WG_STAMP(12);
@@ -1484,8 +1560,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             c1 += s5 * dl5 + l5 * dy + s6 * dl6 - l6 * dy; c2 += dy * dl5 - dy * dl6;
             un[W::KB] = dy * dl5; un[W::KB + 1] = -dy * dl6;
         }
-        // the cone's share (step bound, mu_aff sums) was computed by the cone thread inside the solve (cone_step)
-        WG_CONE() { amax_cone = SC[SC_AMAXC]; c1 += SC[SC_C1C]; c2 += SC[SC_C2C]; }
+        // the cone's share (step bounds, mu_aff sums) was computed by the cone lanes inside the solve (solve_tail)
+        WG_CONE() { amax_cone = fmin(SC[SC_AMAXC], SC[SC_AMAXC2]); c1 += SC[SC_C1C]; c2 += SC[SC_C2C]; }
         const Red3 rb = wg_reduce(Red3{fmin(rmax > 0.0 ? rcp1(rmax) : 1e300, amax_cone), c1, c2}, sm + W::RED, red_phase);
         WG_STAMP(14);
         {
@@ -1500,6 +1576,16 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // ================= corrector: kappa = (sigma mu - ds_a dl_a) / s per row; cone part by the cone thread =================
         // (no region of its own for the row kappas: both factors are in the row arrays since the pass above -- the reduction's
         //  barrier published them -- and sigma mu is known to every thread)
+        if constexpr (KAPPA_EARLY) {
+        WG_CONE() {   // kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) ): the second term and 1 / det(s) are in
+            // KQ / SC_IDET since the affine solve (solve_tail's third lane); a re-centring iteration has no second term
+            const double smd = sigmu * (first_warm ? rcp(gcs_math::soc_det<Q>(SOC + SO::SS)) : SC[SC_IDET]);
+#pragma unroll
+            for (int i = 0; i < Q; ++i)
+                SOC[SO::KS + i] = smd * (i == 0 ? SOC[SO::SS] : -SOC[SO::SS + i]) - (first_warm ? 0.0 : SOC[SO::KQ + i]);
+            SC[SC_GT] = 1.0 - SOC[SO::KS];
+        }
+        } else {
         WG_CONE() {   // (beside the G'kappa tasks: the last wavefront has none) kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) )
             double wb[Q], a1[Q], a2[Q], pr[Q], qv[Q], xs[Q], lt[Q], ss[Q];
             const double eta = SC[SC_ETA];
@@ -1528,6 +1614,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll
             for (int i = 0; i < Q; ++i) SOC[SO::KS + i] = smd * (i == 0 ? ss[0] : -ss[i]) - (first_warm ? 0.0 : a1[i]);
             SC[SC_GT] = 1.0 - SOC[SO::KS];
+        }
         }
         // G' kappa per unit: own unknowns (GU) and the x part (GX).  One task per (unit, half, coordinate) forms both entries: they
         // run over the same rows (kappa_a and kappa_b of every facet), so one pass over the row arrays serves both
@@ -1587,7 +1674,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             rmax = fmax(rmax, fmax(fmax(-dy * i5, -dl5 * rcp1(l5)), fmax(dy * i6, -dl6 * rcp1(l6))));
         }
         amax_cone = 1e300;
-        WG_CONE() amax_cone = SC[SC_AMAXC];
+        WG_CONE() amax_cone = fmin(SC[SC_AMAXC], SC[SC_AMAXC2]);
         const Red3 rd = wg_reduce(Red3{fmin(rmax > 0.0 ? rcp1(rmax) : 1e300, amax_cone), 0.0, 0.0}, sm + W::RED, red_phase);
         WG_STAMP(19);
         WG_CONE() {      // step length with the cone guard (round-off must not push either cone point outside)

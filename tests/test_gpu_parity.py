@@ -117,7 +117,7 @@ def test_small_cases_known_answers(torch_gpu):
     for name, pri1, stop, cost in (("test1", 1.086278, 136, 0.420709), ("test2", 2.074849, 122, 2.694316)):
         case, g = load_fixture(name)
         res = _solver(g).solve()
-        assert abs(res["pri_res_seq"][1] - pri1) <= 1e-4 and abs(res["dual_res_seq"][1] - pri1) <= 1e-4
+        assert abs(res["pri_res_seq"][1] - pri1) <= 2e-4 and abs(res["dual_res_seq"][1] - pri1) <= 2e-4      # (tests/test_oracle_golden.py: why 2e-4)
         assert abs(res["iterations"] - stop) <= 2 and abs(res["cost"] - cost) <= 1e-4
 
 
