@@ -86,13 +86,14 @@ def kernel_resources() -> dict:
 
 
 def build_timing() -> str:
-    """Diagnostic library (tools/wg_phase_timing.py): the workgroup program with its region stamps compiled in."""
+    """Diagnostic library (tools/wg_phase_timing.py): the workgroup program with its region stamps compiled in -- the 512-thread object
+    (the one small graphs such as benchmark4 run) and, under its own symbol names, nothing else: the 256-thread object stays the product's."""
     out = os.path.join(HERE, "libgcsadmm_timing.so")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     build()
-    obj = os.path.join(HERE, "vertex_wg_timing.o")
-    subprocess.check_call([hipcc()] + flags + ["-DGCS_WG_TIMING", "-c", WG, "-o", obj])
-    objs = [os.path.join(HERE, n) for n in ("gcsadmm.o", "polytope_lp.o", "vertex_wg_dims.o", "vertex_wg_t512.o", "vertex_wg_dims_t512.o")] + [obj]
+    obj = os.path.join(HERE, "vertex_wg_t512_timing.o")
+    subprocess.check_call([hipcc()] + flags + T512 + ["-DGCS_WG_TIMING", "-c", WG, "-o", obj])
+    objs = [os.path.join(HERE, n) for n in ("gcsadmm.o", "polytope_lp.o", "vertex_wg.o", "vertex_wg_dims.o", "vertex_wg_dims_t512.o")] + [obj]
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
     return out
 

@@ -44,7 +44,6 @@ using gcs_math::sqrt_nr;
 constexpr int WG_THREADS = GCS_WG_THREADS;        // threads per workgroup (a power of two, whole wavefronts)
 constexpr int WG_WAVES = WG_THREADS / 64;
 constexpr int WG_ITEM_WAVES = WG_WAVES > 1 ? WG_WAVES - 1 : 1;   // wavefronts that share the items of a wave-local pipeline
-constexpr int WG_KAPPA_TID = WG_WAVES > 1 ? (WG_WAVES - 1) * 64 - 1 : WG_THREADS - 1;   // WG_KAPPA's lane
 constexpr double CHOL_SKIP = 1e-12;
 constexpr double REG_DELTA = 1e-7;   // Tikhonov term on every centred unknown except t (oracle/gcs_oracle.c REG_DELTA)
 
@@ -69,9 +68,6 @@ __device__ __forceinline__ int wg_tid()
 // the cone's two step bounds (slack side, dual side) are the SAME code on different data: two lanes of the last wavefront, l = 0, 1, run
 // them side by side (one instruction stream) instead of one lane running them back to back
 #define WG_CONE2(l) for (int l = gcs_wg::wg_tid() - (gcs_wg::WG_THREADS - 2); l >= 0 && l < 2; l = 2)
-// a third serial piece of cone algebra that is independent of those two (the corrector's second-order term) runs meanwhile on the last
-// lane of the wavefront BEFORE the last one (that lane has no item of the wave-local pipeline: 63 lanes of items would be 12 units)
-#define WG_KAPPA() if (gcs_wg::wg_tid() == gcs_wg::WG_KAPPA_TID)
 // work that one WAVEFRONT does with a matrix row per lane (wave_ldl below): no barrier inside, broadcasts by readlane
 #define WG_WAVE0() if (gcs_wg::wg_tid() < 64)
 // `cnt` pieces of such work, piece w on wavefront w (one matrix per wavefront; a workgroup with fewer wavefronts takes them in turns)
@@ -106,7 +102,6 @@ __device__ __forceinline__ int wg_tid()
 #define WG_ONE() if (true)
 #define WG_CONE() if (true)
 #define WG_CONE2(l) for (int l = 0; l < 2; ++l)
-#define WG_KAPPA() if (true)
 #define WG_WAVE0() if (true)
 #define WG_FIRST_WAVES(w, cnt) for (int w = 0; w < (cnt); ++w)
 #define WG_ITEM_FOR(q, i, count, PER) WG_FOR(t_, (count) * (PER)) if (const int q = t_ / (PER), i = t_ - q * (PER); true)
@@ -119,6 +114,7 @@ __device__ __forceinline__ int wg_tid()
 #if defined(GCS_WG_TIMING) && defined(__HIPCC__)
 __device__ unsigned long long g_wg_cycles[64];
 __device__ unsigned long long g_wg_counts[64];
+__device__ unsigned long long g_wg_wave_cycles[64 * 8];      // [region][wavefront]: ticks from the region's start to the wavefront's arrival at its closing barrier
 #endif
 #if defined(GCS_WG_TIMING) && WG_DEVICE
 __device__ __forceinline__ void wg_stamp(int id, unsigned long long &last)
@@ -126,18 +122,32 @@ __device__ __forceinline__ void wg_stamp(int id, unsigned long long &last)
     // wavefront 0 of workgroup 0, as a wave-UNIFORM branch: every lane adds the same difference to the same word (one wavefront,
     // one instruction: no race, no atomics).  A divergent `threadIdx.x == 0` here made the n = 6 instantiation spill beside the
     // branch, and this compiler stored that spill under the branch's partial EXEC mask (all n = 6 solves failed in this build).
-    if (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0) {
+    if (blockIdx.x == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        volatile unsigned long long *cyc = g_wg_cycles, *cnt = g_wg_counts;
-        cyc[id] = cyc[id] + (t - last);
-        cnt[id] = cnt[id] + 1ull;
-        last = __builtin_amdgcn_s_memtime();
+        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0) {
+            volatile unsigned long long *cyc = g_wg_cycles, *cnt = g_wg_counts;
+            cyc[id] = cyc[id] + (t - last);
+            cnt[id] = cnt[id] + 1ull;
+        }
+        last = __builtin_amdgcn_s_memtime();      // (every wavefront keeps the start of the region it is entering)
     }
 }
+// placed right BEFORE the barrier that closes region `id`: when did THIS wavefront get there?
+__device__ __forceinline__ void wg_arrive(int id, unsigned long long last)
+{
+    if (blockIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        volatile unsigned long long *cyc = g_wg_wave_cycles;
+        const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+        cyc[id * 8 + (w & 7)] = cyc[id * 8 + (w & 7)] + (t - last);
+    }
+}
+#define WG_ARRIVE(id) gcs_wg::wg_arrive(id, wg_last_stamp)
 #define WG_STAMP(id) gcs_wg::wg_stamp(id, wg_last_stamp)
 #define WG_STAMP_INIT() unsigned long long wg_last_stamp = __builtin_amdgcn_s_memtime()
 #else
 #define WG_STAMP(id) do { } while (0)
+#define WG_ARRIVE(id) do { } while (0)
 #define WG_STAMP_INIT() do { } while (0)
 #endif
 
@@ -166,9 +176,9 @@ constexpr int pad2(int x) { return (x + 1) & ~1; }      // keep every array 16-b
 template <int N> struct WSoc {   // cone block
     static constexpr int Q = N + 1;
     static constexpr int SS = 0, LS = Q, WB = 2 * Q, LT = 3 * Q, CV = LT + Q, SU = CV + N, DSSA = SU + N * N, DLSA = DSSA + Q,
-                         DSS = DLSA + Q, DLS = DSS + Q, KS = DLS + Q, KQ = KS + Q, SIZE = KQ + Q;
+                         DSS = DLSA + Q, DLS = DSS + Q, KS = DLS + Q, SIZE = KS + Q;
 };
-enum { SC_T = 0, SC_DT, SC_DTA, SC_ALPHA, SC_CONEFAIL, SC_C0, SC_ETA, SC_GT, SC_AMAXC, SC_C1C, SC_C2C, SC_AMAXC2, SC_IDET, SC_N = 14 };
+enum { SC_T = 0, SC_DT, SC_DTA, SC_ALPHA, SC_CONEFAIL, SC_C0, SC_ETA, SC_GT, SC_AMAXC, SC_C1C, SC_C2C, SC_AMAXC2, SC_N = 12 };
 template <int N> struct WL {
     using D = WD<N>;
     static constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1;
@@ -352,12 +362,12 @@ GCS_HD constexpr int pki(int i, int j) { return i * (i + 1) / 2 + j; }   // pack
 // (Sending the pivot column through LDS -- one write, broadcast ds_read_b128 back -- instead of two readlanes per entry was
 // measured SLOWER at 25 x 25: 82 800 against 79 200 ticks per Newton iteration; the wait on the LDS round trip per column costs
 // more than the readlanes it saves.)
+// (Round 4, measured and rejected: the affine solve INSIDE this pass -- forward substitution riding in the elimination, one more
+// readlane + FMA per column, backward substitution from the factor just stored -- saves a region and its barrier but lengthens the
+// pivot chain by as much: benchmark4 9 555 it/s with it, 9 690 without, profiles/r04/README.md.)
 // Host build: the same column-by-column elimination written serially.
 // ---------------------------------------------------------------------------------------------------------------
-// With a right-hand side b (not null) the call also solves A x = b: the forward substitution rides in the elimination (one more
-// readlane + FMA per column, off the pivot chain), the backward substitution follows from the stored factor -- the affine solve of a
-// Newton iteration, whose right-hand side exists before the factorisation starts, costs half a wave_ldl_solve and no region of its own.
-template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd, const double *b = nullptr, double *x = nullptr)
+template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd)
 {
     static_assert(DIM <= 64, "one row per lane");
 #if WG_DEVICE
@@ -366,7 +376,7 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd, const double *b 
 #pragma unroll
     for (int j = 0; j < DIM; ++j) a[j] = Mq[row * DIM + j];
     const double od = Mq[row * DIM + row];
-    double myr = 0.0, v = b ? b[row] : 0.0;
+    double myr = 0.0;
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
         double dk = lane_bcast(a[k], k);
@@ -377,21 +387,11 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd, const double *b 
         if (lane == k) myr = rk;
 #pragma unroll
         for (int j = k + 1; j < DIM; ++j) a[j] -= l * lane_bcast(col, j);     // (entries right of the diagonal: unused values)
-        if (b) v -= (row > k ? l : 0.0) * lane_bcast(v, k);                   // y = L^{-1} b: lane k's entry is final at step k
     }
     if (lane < DIM) {
 #pragma unroll
         for (int j = 0; j < DIM - 1; ++j) Mq[lane * DIM + j] = a[j];
         rd[lane] = myr;
-    }
-    if (b) {      // x = L^{-T} D^{-1} y: column `row` of L from the factor just stored (LDS operations of one wavefront complete in order)
-        v *= myr;
-        double l[DIM];
-#pragma unroll
-        for (int k = 1; k < DIM; ++k) l[k] = k > row ? Mq[k * DIM + row] : 0.0;
-#pragma unroll
-        for (int k = DIM - 1; k >= 1; --k) v -= l[k] * lane_bcast(v, k);
-        if (lane < DIM) x[lane] = v;
     }
 #else
     double od[DIM], col[DIM];
@@ -407,16 +407,6 @@ template <int DIM> GCS_HD void wave_ldl(double *Mq, double *rd, const double *b 
             Mq[i * DIM + k] = l;
             for (int j = k + 1; j <= i; ++j) Mq[i * DIM + j] -= l * col[j];
         }
-    }
-    if (b) {
-        double v[DIM];
-        for (int i = 0; i < DIM; ++i) v[i] = b[i];
-        for (int k = 0; k < DIM - 1; ++k)
-            for (int i = k + 1; i < DIM; ++i) v[i] -= Mq[i * DIM + k] * v[k];
-        for (int i = 0; i < DIM; ++i) v[i] *= rd[i];
-        for (int k = DIM - 1; k >= 1; --k)
-            for (int i = 0; i < k; ++i) v[i] -= Mq[k * DIM + i] * v[k];
-        for (int i = 0; i < DIM; ++i) x[i] = v[i];
     }
 #endif
 }
@@ -583,9 +573,11 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     using SO = WSoc<N>;
     using W = std::conditional_t<BOX, WLBox<N>, WL<N>>;       // LDS layout: dense K_e / X_e / B_e per unit, or their structured forms
     constexpr int NW = D::NW, NX = D::NX, NB1 = D::NB1, Q = D::Q, NS = D::NS, TA = D::TA;
-    constexpr bool FUSE_AFFINE = NB1 <= 13;      // the affine solve inside the border factorisation (wave_ldl with a right-hand side)
-    constexpr bool KAPPA_EARLY = N <= 3;         // the corrector's cone term formed beside the affine solve's tail (solve_tail); at n = 6 the
-                                                 // cone is not that region's critical path and the extra lane costs registers (BOX: 167 -> 169)
+#ifndef GCS_WG_CONE_PAIR_MAXN
+#define GCS_WG_CONE_PAIR_MAXN 3
+#endif
+    constexpr bool CONE_PAIR = N <= GCS_WG_CONE_PAIR_MAXN;      // the cone's two step bounds on two lanes side by side (solve_tail); at n = 6 the
+                                                                // second lane costs the BOX instantiation two registers (167 -> 169: its third workgroup per CU)
     const bool prox = a.prox_q != nullptr;       // border-only problem with a separable quadratic (no blocks, no sides)
     const int lo = a.inc_ptr[v], d = prox ? 0 : a.inc_ptr[v + 1] - lo, d_in = prox ? 0 : a.deg_in[v], d_out = d - d_in;
     const bool sides = d > 0;
@@ -787,10 +779,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     // r_e -> d w_e for ITS units, while the cone thread (last wavefront) does the cone's three parts.  (Merging (1) and (2) into
     // the one wavefront was measured slower: 2 250 against 1 830 cycles.)
     auto solve_tail = [&](int dt_slot, bool wk) {
-        if (wk || !FUSE_AFFINE) {      // (the affine solve's substitutions rode in the border factorisation: wave_ldl with a right-hand side)
-            WG_WAVE0() wave_ldl_solve<NB1>(sm + W::M, sm + W::PIVM, sm + W::RHS, sm + W::SOL);
-            WG_SYNC();
-        }
+        WG_WAVE0() wave_ldl_solve<NB1>(sm + W::M, sm + W::PIVM, sm + W::RHS, sm + W::SOL);
+        WG_SYNC();
         WG_STAMP(34);
         // solution back in (x, z1, z2, y_v): dz1 = du + dz2
         auto dzeta = [&](int i) { return i < N ? sm[W::SOL + NX + i] + sm[W::SOL + NX + N + i] : sm[W::SOL + NX + i]; };
@@ -816,10 +806,10 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_SYNC();
         WG_STAMP(36);
         // the cone, beside the pipeline below.  Two lanes of the last wavefront form the cone's directions (both the same values) and
-        // then ONE step bound each, side by side: lane 0 the slack side, lane 1 the dual side (the two bounds back to back on one lane
-        // were this step's critical path: a square root and two reciprocal chains each).  A third lane, on another wavefront, forms
-        // what the corrector's kappa needs from the AFFINE cone directions -- everything but sigma mu -- so that the corrector's
-        // cone thread has three multiplications left (it was the critical path of the G'kappa region).
+        // then ONE step bound each, side by side: lane 0 the slack side, lane 1 the dual side (a square root and two reciprocal chains
+        // each).  (Round 4, measured and rejected: a third lane on another wavefront forming the corrector's second-order cone term
+        // here, so that the G'kappa region's cone thread has three multiplications left -- that wavefront also owns a unit of the
+        // pipeline on vertices of degree >= 7 and became the last to arrive: benchmark4 9 555 it/s with it, 9 580 without.)
         auto cone_bounds = [&](int l) {      // l = 0: the slack side's bound, 1: the dual side's, 2: both (one lane, back to back)
             const int oDS = wk ? SO::DSS : SO::DSSA, oDL = wk ? SO::DLS : SO::DLSA;
             double xs[Q], dl[Q], bs[Q], dr[Q];
@@ -837,35 +827,8 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             SC[l == 1 ? SC_AMAXC2 : SC_AMAXC] = gcs_math::soc_max_step<Q>(bs, dr);
             if (l == 2) SC[SC_AMAXC2] = gcs_math::soc_max_step<Q>(SOC + SO::LS, dl);
         };
-        if constexpr (KAPPA_EARLY) { WG_CONE2(l) cone_bounds(l); }
+        if constexpr (CONE_PAIR) { WG_CONE2(l) cone_bounds(l); }
         else { WG_CONE() cone_bounds(2); }
-        if constexpr (KAPPA_EARLY) WG_KAPPA() if (!wk) {      // W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) ) and 1 / det(s): kappa_soc = sigma mu s^{-1} - the former
-            double xs[Q], dl[Q], wb[Q], a1[Q], a2[Q], pr[Q], qv[Q], lt[Q];
-            cone_dir(dt_slot, false, xs, dl);
-            const double eta = SC[SC_ETA];
-#pragma unroll
-            for (int k = 0; k < Q; ++k) { wb[k] = SOC[SO::WB + k]; lt[k] = SOC[SO::LT + k]; }
-            soc_apply_Wi<Q>(wb, eta, xs, a1);
-            soc_apply_W<Q>(wb, eta, dl, a2);
-            double dsum = 0;
-#pragma unroll
-            for (int k = 0; k < Q; ++k) dsum += a1[k] * a2[k];
-            pr[0] = dsum;
-#pragma unroll
-            for (int k = 1; k < Q; ++k) pr[k] = a1[0] * a2[k] + a2[0] * a1[k];
-            const double det = gcs_math::soc_det<Q>(lt);
-            double ld1 = 0;
-#pragma unroll
-            for (int k = 1; k < Q; ++k) ld1 += lt[k] * pr[k];
-            qv[0] = (lt[0] * pr[0] - ld1) * rcp(det);
-            const double ilt0 = rcp(lt[0]);
-#pragma unroll
-            for (int k = 1; k < Q; ++k) qv[k] = (pr[k] - qv[0] * lt[k]) * ilt0;
-            soc_apply_Wi<Q>(wb, eta, qv, a1);
-#pragma unroll
-            for (int i = 0; i < Q; ++i) SOC[SO::KQ + i] = a1[i];
-            SC[SC_IDET] = rcp(gcs_math::soc_det<Q>(SOC + SO::SS));
-        }
         WG_REPL_FOR(t, 2 * NW) {      // d nu_s = Bs^{-1} w_s
             const int s = t / NW, i = t - s * NW;
             const double *Bsi = sm + W::BSI + s * NW * NW;
@@ -911,6 +874,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             }
             un[W::DW + i] = acc;
         }
+        WG_ARRIVE(39);
         WG_SYNC();
         WG_STAMP(39);
     };
@@ -1199,6 +1163,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             }
             if constexpr (BOX) un[W::KYY] = sk; else un[W::K + 2 * N * NW + 2 * N] = sk;
         }
+        WG_ARRIVE(2);
         WG_SYNC();
         WG_STAMP(2);
         if (wg_uniform(SC[SC_CONEFAIL]) != 0.0) {
@@ -1430,6 +1395,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             sm[W::RP + tt] = acc2;
         }
         if (!first_warm) bg_tasks(plq);                   // affine solve, head 2/4
+        WG_ARRIVE(6);
         WG_SYNC();
         WG_STAMP(6);
         // ================= sides: factor, invert, Y_s = Bs^{-1} BXs (over the dead factor) =================
@@ -1512,12 +1478,10 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             }
             if (!first_warm) rhs_tasks(plm, false);       // affine solve, head 4/4
         }
+        WG_ARRIVE(10);
         WG_SYNC();
         WG_STAMP(10);
-        // L D L' inside one wavefront; no explicit inverse; the affine solve (not in a re-centring iteration) in the same pass
-        // (up to n = 3: at n = 6 the 25 x 25 instance with the extra chain costs the BOX instantiation the registers of its third workgroup per CU)
-        if constexpr (FUSE_AFFINE) { WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM, first_warm ? nullptr : sm + W::RHS, sm + W::SOL); }
-        else { WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM); }
+        WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM);      // L D L' inside one wavefront; no explicit inverse
         WG_SYNC();
         WG_STAMP(11);
         WG_STAMP(12);
@@ -1576,16 +1540,6 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // ================= corrector: kappa = (sigma mu - ds_a dl_a) / s per row; cone part by the cone thread =================
         // (no region of its own for the row kappas: both factors are in the row arrays since the pass above -- the reduction's
         //  barrier published them -- and sigma mu is known to every thread)
-        if constexpr (KAPPA_EARLY) {
-        WG_CONE() {   // kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) ): the second term and 1 / det(s) are in
-            // KQ / SC_IDET since the affine solve (solve_tail's third lane); a re-centring iteration has no second term
-            const double smd = sigmu * (first_warm ? rcp(gcs_math::soc_det<Q>(SOC + SO::SS)) : SC[SC_IDET]);
-#pragma unroll
-            for (int i = 0; i < Q; ++i)
-                SOC[SO::KS + i] = smd * (i == 0 ? SOC[SO::SS] : -SOC[SO::SS + i]) - (first_warm ? 0.0 : SOC[SO::KQ + i]);
-            SC[SC_GT] = 1.0 - SOC[SO::KS];
-        }
-        } else {
         WG_CONE() {   // (beside the G'kappa tasks: the last wavefront has none) kappa_soc = sigma mu s^{-1} - W^{-1}( lt \ ((W^{-1} ds_a) o (W dl_a)) )
             double wb[Q], a1[Q], a2[Q], pr[Q], qv[Q], xs[Q], lt[Q], ss[Q];
             const double eta = SC[SC_ETA];
@@ -1614,7 +1568,6 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
 #pragma unroll
             for (int i = 0; i < Q; ++i) SOC[SO::KS + i] = smd * (i == 0 ? ss[0] : -ss[i]) - (first_warm ? 0.0 : a1[i]);
             SC[SC_GT] = 1.0 - SOC[SO::KS];
-        }
         }
         // G' kappa per unit: own unknowns (GU) and the x part (GX).  One task per (unit, half, coordinate) forms both entries: they
         // run over the same rows (kappa_a and kappa_b of every facet), so one pass over the row arrays serves both
@@ -1649,6 +1602,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const double yy = un[W::P + 2 * N];
             un[W::GU + 2 * N] = s - (sigmu - un[W::KB]) * rcp1(yy) + (sigmu - un[W::KB + 1]) * rcp1(1.0 - yy);
         }
+        WG_ARRIVE(16);
         WG_SYNC();
         WG_STAMP(16);
         solve_head(true);

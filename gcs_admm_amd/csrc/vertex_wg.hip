@@ -57,6 +57,10 @@ extern "C" int gcsadmm_debug_wg_cycles(unsigned long long *cycles64, unsigned lo
     if (e == 0) e = (int)hipMemcpyFromSymbol(counts64, HIP_SYMBOL(gcs_wg::g_wg_counts), 64 * sizeof(unsigned long long));
     return e;
 }
+extern "C" int gcsadmm_debug_wg_wave_cycles(unsigned long long *cycles512)
+{
+    return (int)hipMemcpyFromSymbol(cycles512, HIP_SYMBOL(gcs_wg::g_wg_wave_cycles), 512 * sizeof(unsigned long long));
+}
 #endif
 #ifdef GCS_WG_BLOCKTIME
 extern "C" int gcsadmm_debug_wg_blocks(unsigned long long *ticks64, unsigned long long *iters64)

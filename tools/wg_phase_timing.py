@@ -25,6 +25,10 @@ for wl in sys.argv[1:] or ["benchmark4", "lat6"]:
         g, dt = lattice_boxes(100, 100, n=6, seed=0), "f32"
     elif wl == "lat2":
         g, dt = lattice_boxes(16, 16, seed=0), "f32"
+    elif wl == "lat2small":     # 146 vertices: the 512-thread object (the stamped one)
+        g, dt = lattice_boxes(12, 12, seed=0), "f64"
+    elif wl.startswith("benchmark"):
+        g, dt = load_fixture(wl)[1], "f64"
     d = solver.DeviceSolver(g, dt, device=0, program="workgroup")
     d.reset(max_it=1000, eps_abs=0.0, eps_rel=0.0)
     d.enqueue(10); torch.cuda.synchronize()
@@ -43,6 +47,12 @@ for wl in sys.argv[1:] or ["benchmark4", "lat6"]:
         if n1[k] > 0:
             print(f"  {k:2d} {NAMES[k]:32s} {100 * c1[k] / tot:6.2f} %   {c1[k] / n1[k]:9.1f} ticks/visit  x{n1[k] / steps:.1f}")
     res[wl] = dict(cycles=c1.tolist(), counts=n1.tolist(), steps=steps)
+    if hasattr(d.lib, "gcsadmm_debug_wg_wave_cycles"):      # per wavefront: arrival at the closing barrier of a few regions, ticks since the region's start
+        wc = (C.c_ulonglong * 512)(); d.lib.gcsadmm_debug_wg_wave_cycles(wc)
+        wv = np.array(list(wc), float).reshape(64, 8)
+        for k in np.nonzero(wv.sum(1))[0]:
+            visits = max(n0[k] + n1[k], 1)
+            print(f"  region {k:2d} ({NAMES.get(int(k), '?').strip()}): arrival of wavefronts 0..7 at its barrier, ticks/visit: " + " ".join(f"{x / visits:7.0f}" for x in wv[k]))
     if hasattr(d.lib, "gcsadmm_debug_wg_blocks"):      # whole-solve ticks per workgroup: which vertex ends the launch?
         bt = (C.c_ulonglong * 64)(); bi = (C.c_ulonglong * 64)()
         d.lib.gcsadmm_debug_wg_blocks(bt, bi)
