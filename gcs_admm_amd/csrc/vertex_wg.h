@@ -119,27 +119,26 @@ __device__ unsigned long long g_wg_wave_cycles[64 * 8];      // [region][wavefro
 #if defined(GCS_WG_TIMING) && WG_DEVICE
 __device__ __forceinline__ void wg_stamp(int id, unsigned long long &last)
 {
-    // wavefront 0 of workgroup 0, as a wave-UNIFORM branch: every lane adds the same difference to the same word (one wavefront,
-    // one instruction: no race, no atomics).  A divergent `threadIdx.x == 0` here made the n = 6 instantiation spill beside the
-    // branch, and this compiler stored that spill under the branch's partial EXEC mask (all n = 6 solves failed in this build).
+    // workgroup 0 only (a uniform branch).  Every wavefront takes the time right after the barrier that closed region `id` -- the
+    // common origin of the next region; lane 0 of wavefront 0 adds the region's length with NON-RETURNING atomics (nothing waits for
+    // them: the volatile read-modify-write of earlier rounds held wavefront 0 back by ~1 100 cycles per stamp, which the other
+    // wavefronts then waited for at the next barrier).  (n = 6: a divergent branch here once made that instantiation spill beside
+    // it, and this compiler stored the spill under the branch's partial EXEC mask; the timing build is a tool for n = 2, 3.)
     if (blockIdx.x == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0) {
-            volatile unsigned long long *cyc = g_wg_cycles, *cnt = g_wg_counts;
-            cyc[id] = cyc[id] + (t - last);
-            cnt[id] = cnt[id] + 1ull;
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_wg_cycles[id], t - last);
+            atomicAdd(&g_wg_counts[id], 1ull);
         }
-        last = __builtin_amdgcn_s_memtime();      // (every wavefront keeps the start of the region it is entering)
+        last = t;
     }
 }
-// placed right BEFORE the barrier that closes region `id`: when did THIS wavefront get there?
+// placed right BEFORE the barrier that closes region `id`: when did THIS wavefront get there (ticks since the region's start)?
 __device__ __forceinline__ void wg_arrive(int id, unsigned long long last)
 {
     if (blockIdx.x == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        volatile unsigned long long *cyc = g_wg_wave_cycles;
-        const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
-        cyc[id * 8 + (w & 7)] = cyc[id * 8 + (w & 7)] + (t - last);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_wg_wave_cycles[id * 8 + ((threadIdx.x >> 6) & 7)], t - last);
     }
 }
 #define WG_ARRIVE(id) gcs_wg::wg_arrive(id, wg_last_stamp)
@@ -748,15 +747,19 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 }
             }
         }
+        WG_ARRIVE(30);
         WG_SYNC();
         WG_STAMP(30);
         { Place pl; bg_tasks(pl); }
+        WG_ARRIVE(31);
         WG_SYNC();
         WG_STAMP(31);
         { Place pl; v_tasks(pl); }
+        WG_ARRIVE(32);
         WG_SYNC();
         WG_STAMP(32);
         { Place pl; rhs_tasks(pl, wk); }
+        WG_ARRIVE(33);
         WG_SYNC();
         WG_STAMP(33);
     };
@@ -780,6 +783,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
     // the one wavefront was measured slower: 2 250 against 1 830 cycles.)
     auto solve_tail = [&](int dt_slot, bool wk) {
         WG_WAVE0() wave_ldl_solve<NB1>(sm + W::M, sm + W::PIVM, sm + W::RHS, sm + W::SOL);
+        WG_ARRIVE(34);
         WG_SYNC();
         WG_STAMP(34);
         // solution back in (x, z1, z2, y_v): dz1 = du + dz2
@@ -803,6 +807,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 SC[dt_slot] = acc * rcp(SC[SC_C0]);
             }
         }
+        WG_ARRIVE(36);
         WG_SYNC();
         WG_STAMP(36);
         // the cone, beside the pipeline below.  Two lanes of the last wavefront form the cone's directions (both the same values) and
@@ -1004,6 +1009,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             for (int k = 0; k < Q; ++k) acc += SOC[SO::SS + k] * SOC[SO::LS + k];
             if (!gcs_math::soc_interior<Q>(SOC + SO::SS)) bad = 1;
         }
+        WG_ARRIVE(1);
         const Red3 r0 = wg_reduce(Red3{bad ? -1.0 : 1.0, acc, 0.0}, sm + W::RED, red_phase);
         WG_STAMP(1);
         // (workgroup-uniform scalars go to scalar registers: the branches on them are then scalar branches, not EXEC-masked regions)
@@ -1260,6 +1266,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             un[W::RV + h] = ch;
             }
         }
+        WG_ARRIVE(3);
         WG_SYNC();
         WG_STAMP(3);
         if constexpr (BOX) {
@@ -1277,6 +1284,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                     un[W::BW + 2 * N] = -1.0;
                 }
             }
+            WG_ARRIVE(4);
             WG_SYNC();
             WG_STAMP(4);
             if (!first_warm) {      // affine solve, head 1/4 (a re-centring iteration has no affine solve: none of its four head steps)
@@ -1296,6 +1304,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             const double base = (i < 2 * N && j < 2 * N && i / N == j / N) ? un[W::B + ij] : 0.0;
             un[W::B + ij] = base + wi * wj * rs;
         }
+        WG_ARRIVE(4);
         WG_SYNC();
         WG_STAMP(4);
         Place plx;
@@ -1308,6 +1317,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             un[W::K + ic] = s;
         }
         if (!first_warm) te_tasks(plx, false);            // affine solve, head 1/4
+        WG_ARRIVE(5);
         WG_SYNC();
         WG_STAMP(5);
         }
@@ -1403,6 +1413,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         if (sides) {
             // B_in and B_out = L D L' concurrently, one wavefront each, one matrix row per lane (one call site: one copy of the code)
             WG_FIRST_WAVES(sd, 2) wave_ldl<NW>(sm + W::BS + sd * NW * NW, sm + W::PIVS + sd * NW);
+            WG_ARRIVE(7);
             WG_SYNC();
             WG_STAMP(7);
             WG_FOR(t, 2 * NW) {
@@ -1425,6 +1436,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             WG_SYNC();
         }
         if (!first_warm) v_tasks(ply);                    // affine solve, head 3/4
+        WG_ARRIVE(9);
         WG_SYNC();
         WG_STAMP(9);
         // ================= reduced border matrix in the (x, u, z2, y_v) variables =================
@@ -1482,6 +1494,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         WG_SYNC();
         WG_STAMP(10);
         WG_WAVE0() wave_ldl<NB1>(sm + W::M, sm + W::PIVM);      // L D L' inside one wavefront; no explicit inverse
+        WG_ARRIVE(11);
         WG_SYNC();
         WG_STAMP(11);
         WG_STAMP(12);
@@ -1498,6 +1511,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             WG_ROWS_END()
             WG_FOR_AT(u, U, plb.at(U)) { double *un = UN(u); un[W::KB] = 0.0; un[W::KB + 1] = 0.0; }
             sigmu = mu_ref;
+            WG_ARRIVE(14);
             WG_SYNC();
             WG_STAMP(14);
         } else {
@@ -1526,6 +1540,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         // the cone's share (step bounds, mu_aff sums) was computed by the cone lanes inside the solve (solve_tail)
         WG_CONE() { amax_cone = fmin(SC[SC_AMAXC], SC[SC_AMAXC2]); c1 += SC[SC_C1C]; c2 += SC[SC_C2C]; }
+        WG_ARRIVE(14);
         const Red3 rb = wg_reduce(Red3{fmin(rmax > 0.0 ? rcp1(rmax) : 1e300, amax_cone), c1, c2}, sm + W::RED, red_phase);
         WG_STAMP(14);
         {
@@ -1629,6 +1644,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         }
         amax_cone = 1e300;
         WG_CONE() amax_cone = fmin(SC[SC_AMAXC], SC[SC_AMAXC2]);
+        WG_ARRIVE(19);
         const Red3 rd = wg_reduce(Red3{fmin(rmax > 0.0 ? rcp1(rmax) : 1e300, amax_cone), 0.0, 0.0}, sm + W::RED, red_phase);
         WG_STAMP(19);
         WG_CONE() {      // step length with the cone guard (round-off must not push either cone point outside)
@@ -1642,6 +1658,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             }
             SC[SC_ALPHA] = al;
         }
+        WG_ARRIVE(20);
         WG_SYNC();
         WG_STAMP(20);
         const double alpha = wg_uniform(SC[SC_ALPHA]);
@@ -1669,6 +1686,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
             SC[SC_T] += alpha * SC[SC_DT];
             for (int k = 0; k < Q; ++k) SOC[SO::LS + k] += alpha * SOC[SO::DLS + k];
         }
+        WG_ARRIVE(21);
         WG_SYNC();
         WG_STAMP(21);
     }
