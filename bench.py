@@ -174,16 +174,22 @@ def cpu_baseline(g, workload, first, warmup, steps, seconds=20.0, dev=None, to_s
            "sample": f"iterations {w_first}..{first + warmup + steps} of the same run (oracle/gcs_oracle.c: vertex solves with the same warm start as the "
                      f"HIP path, OpenMP over vertices; edge step, dual update, norms and loop control serial, as in the reference), the window repeated "
                      f"{len(reps)} x from a snapshot, {cores} threads (best of a sweep up to {ncpu})"}
-    if to_stop:
-        runs = []
-        for _ in range(3):
-            oo = Oracle(g, ipm_tol=IPM_TOL)
-            t0 = time.perf_counter()
-            r = oo.run(nthreads=cores)
-            runs.append((time.perf_counter() - t0, r["iterations"]))
-        runs.sort()
-        out["to_stop"] = {"iterations": runs[1][1], "wall_time_s": runs[1][0], "iterations_per_sec": runs[1][1] / runs[1][0],
-                          "runs": 3, "selection": "median wall time", "all_wall_times_s": [r[0] for r in runs]}
+    if to_stop:      # the whole run from the zero state to the reference's stop rule: its own thread sweep (the best count for a 20-iteration
+        # window of cheap solves is not the best for a run that starts with cold ones), median of three runs at each count
+        best = None
+        for th in sorted(rates):
+            runs = []
+            for _ in range(3):
+                oo = Oracle(g, ipm_tol=IPM_TOL)
+                t0 = time.perf_counter()
+                r = oo.run(nthreads=th)
+                runs.append((time.perf_counter() - t0, r["iterations"]))
+            runs.sort()
+            if best is None or runs[1][0] < best[1][1][0]:
+                best = (th, runs)
+        th, runs = best
+        out["to_stop"] = {"iterations": runs[1][1], "wall_time_s": runs[1][0], "iterations_per_sec": runs[1][1] / runs[1][0], "cores": th,
+                          "runs": 3, "selection": "median wall time at the best thread count of the sweep", "all_wall_times_s": [r[0] for r in runs]}
     return out
 
 

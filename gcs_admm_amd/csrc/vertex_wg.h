@@ -235,6 +235,8 @@ inline int wg_lds_doubles_n(int n, int U, int m, bool box = false)
     }
 }
 
+struct alignas(8) WgF2 { float a, b; };      // two row duals of a warm-start record (warm_start.h: f32)
+
 template <class T> struct WgArgs {
     int n_vtx;                  // generic vertices handled by this launch, one workgroup each
     const int *vtx;             // [n_vtx] vertex ids, heaviest first
@@ -641,7 +643,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         if (use_warm) mu_ref = wg_uniform(fmax(gcs_ws::WS_MU_MIN, gcs_ws::WS_KAPPA * ws_dT));
     }
     const bool ws_started_warm = use_warm;
-    const float inv_R = 1.0f / (float)R;
+    const float inv_R2 = 1.0f / (float)(R / 2);
 
     WG_STAMP(0);
     // gradient entry k of unit u for the Newton right-hand side: smooth part G0, plus (corrector solve) G'kappa of the unit's
@@ -907,9 +909,10 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 const int u = t / NW, k = t - u * NW;
                 UN(u)[W::P + k] = wu[u * WUS + WR::P + k];
             }
-            WG_FOR_AT(t, U * R, pls.at(U * R)) {
-                const int u = fdiv(t, inv_R), r = t - u * R;
-                UN(u)[oLAM + r] = wu[u * WUS + WR::LAM + r];
+            WG_FOR_AT(t, U * (R / 2), pls.at(U * (R / 2))) {      // row duals: f32 in the record, two per 8-byte word (R = 4m is even)
+                const int u = fdiv(t, inv_R2), r2 = t - u * (R / 2);
+                const WgF2 v = reinterpret_cast<const WgF2 *>(wu + u * WUS + WR::LAM)[r2];
+                UN(u)[oLAM + 2 * r2] = (double)v.a; UN(u)[oLAM + 2 * r2 + 1] = (double)v.b;
             }
             WG_FOR_AT(t, 2 * U, pls.at(2 * U)) UN(t >> 1)[W::LB + (t & 1)] = wu[(t >> 1) * WUS + WR::LB + (t & 1)];
             WG_FOR_AT(k, NX + 2 * NW, pls.at(NX + 2 * NW)) {
@@ -1026,9 +1029,10 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 wu[u * WUS + WR::P + k] = UN(u)[W::P + k];
                 if (u > 0) wu[u * WUS + WR::TG + k] = UN(u)[W::TG + k];      // (unit 0, the border, has no targets)
             }
-            WG_FOR_AT(t, U * R, plv.at(U * R)) {
-                const int u = fdiv(t, inv_R), r = t - u * R;
-                wu[u * WUS + WR::LAM + r] = UN(u)[oLAM + r];
+            WG_FOR_AT(t, U * (R / 2), plv.at(U * (R / 2))) {
+                const int u = fdiv(t, inv_R2), r2 = t - u * (R / 2);
+                WgF2 v; v.a = (float)UN(u)[oLAM + 2 * r2]; v.b = (float)UN(u)[oLAM + 2 * r2 + 1];
+                reinterpret_cast<WgF2 *>(wu + u * WUS + WR::LAM)[r2] = v;
             }
             WG_FOR_AT(t, 2 * U, plv.at(2 * U)) wu[(t >> 1) * WUS + WR::LB + (t & 1)] = UN(t >> 1)[W::LB + (t & 1)];
             WG_FOR_AT(k, NX + 2 * NW, plv.at(NX + 2 * NW)) {

@@ -20,8 +20,11 @@
 //             slowest solve.)
 // Record of one vertex with d incident edges and m facets, in doubles (wd_* below):
 //   [0] valid  [1] rho  [2] theta_v  [3] n_cold   | x_v (2n) | nu (2 (2n+1)) | pad |      (t and the cone's dual are re-centred at the restart: not kept)
-//   unit 0 .. d (unit 0 = border (z_v, y_v), unit e = block (O_e, y_e)):  p (2n+1) | bound duals (2) | targets (2n+1) | row duals (4m)
-//   row duals in the order  type (a: rows 1/3, b: rows 2/4) x half x facet.
+//   unit 0 .. d (unit 0 = border (z_v, y_v), unit e = block (O_e, y_e)):  p (2n+1) | bound duals (2) | targets (2n+1) | row duals (4m, as FLOATS)
+//   row duals in the order  type (a: rows 1/3, b: rows 2/4) x half x facet.  They are kept in f32 (round 4): they are two thirds of a record and
+//   a restart does not need more of them -- its first iteration re-centres the iterate at mu_ref >= 1e-7 anyway, and a relative 6e-8 on a dual
+//   moves s o lambda by as much; the primal point, the multipliers of the equalities and the targets stay f64 (a slack can be ~1e-6: its
+//   positivity must survive the round trip).  2.2 -> 1.6 KB per vertex on the n = 2 lattices, 5.8 -> 4.1 KB at n = 6.
 #pragma once
 #include <stdint.h>
 
@@ -60,14 +63,14 @@ template <int N> struct WRec {
     static constexpr int NW = 2 * N + 1, NX = 2 * N, Q = N + 1;
     static constexpr int XV = WD_HDR, NU = XV + NX, UNITS = wd_pad2(NU + 2 * NW);
     // within a unit
-    static constexpr int P = 0, LB = NW, TG = NW + 2, LAM = 2 * NW + 2;
-    static constexpr int unit_stride(int m) { return 2 * NW + 2 + 4 * m; }
+    static constexpr int P = 0, LB = NW, TG = NW + 2, LAM = 2 * NW + 2;      // LAM: 4m floats (= 2m doubles)
+    static constexpr int unit_stride(int m) { return 2 * NW + 2 + 2 * m; }
     static constexpr long long doubles(int m, int d) { return UNITS + (long long)(d + 1) * unit_stride(m); }
 };
 inline long long warm_record_doubles(int n, int m, int d)
 {
     const int NW = 2 * n + 1;
-    return wd_pad2(WD_HDR + 2 * n + 2 * NW) + (long long)(d + 1) * (2 * NW + 2 + 4 * m);
+    return wd_pad2(WD_HDR + 2 * n + 2 * NW) + (long long)(d + 1) * (2 * NW + 2 + 2 * m);
 }
 
 }  // namespace gcs_ws

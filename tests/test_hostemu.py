@@ -42,7 +42,7 @@ class WarmRecords:
     def __init__(self, g):
         n, NW = g.n, 2 * g.n + 1
         deg = np.diff(g.inc_ptr).astype(np.int64); m = np.diff(g.poly_ptr).astype(np.int64)
-        size = ((4 + 2 * n + 2 * NW + 1) & ~1) + (deg + 1) * (2 * NW + 2 + 4 * m)
+        size = ((4 + 2 * n + 2 * NW + 1) & ~1) + (deg + 1) * (2 * NW + 2 + 2 * m)
         self.ptr = np.concatenate([[0], np.cumsum(size)]).astype(np.int64)
         self.buf = np.zeros(int(self.ptr[-1]))
 
@@ -198,10 +198,10 @@ def test_failed_warm_solve_is_repeated_cold_in_the_same_step(emu, oracle_lib):
     v = gen[1]
     n, NW = g.n, 2 * g.n + 1
     m, d = g.poly_ptr[v + 1] - g.poly_ptr[v], g.inc_ptr[v + 1] - g.inc_ptr[v]
-    units, stride = (4 + 2 * n + 2 * NW + 1) & ~1, 2 * NW + 2 + 4 * m
+    units, stride = (4 + 2 * n + 2 * NW + 1) & ~1, 2 * NW + 2 + 2 * m      # (4m row duals as f32: warm_start.h)
     assert w.buf[w.ptr[v]] == 1.0
     for u in range(d + 1):
-        w.buf[w.ptr[v] + units + u * stride + 2 * NW + 2:w.ptr[v] + units + (u + 1) * stride] = -1.0
+        w.buf[w.ptr[v] + units + u * stride + 2 * NW + 2:w.ptr[v] + units + (u + 1) * stride].view(np.float32)[:] = -1.0
     a = emu_step(emu, g, o.zedge, o.mu, 1.0, 1.0, warm=w)
     assert a[4][0] == 0                                # no inner failure
     cols = slice(g.inc_ptr[v], g.inc_ptr[v + 1])

@@ -168,10 +168,10 @@ def test_failed_warm_solve_is_repeated_cold(libs, oracle_lib):
     n, NW = g.n, 2 * g.n + 1
     for v in np.nonzero(gen)[0]:                  # spoil the row duals of every unit (layout: warm_start.h): negative
         m, d = g.poly_ptr[v + 1] - g.poly_ptr[v], g.inc_ptr[v + 1] - g.inc_ptr[v]
-        units, stride = (4 + 2 * n + 2 * NW + 1) & ~1, 2 * NW + 2 + 4 * m
+        units, stride = (4 + 2 * n + 2 * NW + 1) & ~1, 2 * NW + 2 + 2 * m      # (4m row duals as f32: warm_start.h)
         assert w.ptr[v + 1] - w.ptr[v] == units + (d + 1) * stride
         for u in range(d + 1):
-            w.buf[w.ptr[v] + units + u * stride + 2 * NW + 2:w.ptr[v] + units + (u + 1) * stride] = -1.0
+            w.buf[w.ptr[v] + units + u * stride + 2 * NW + 2:w.ptr[v] + units + (u + 1) * stride].view(np.float32)[:] = -1.0
     a = wg_step(fwd, "wg_emu_vertex_step", g, o.zedge, o.mu, warm=w)
     assert a[4][0] == 0 and (a[6][gen] == 0).all()
     assert (a[7][gen] >= cold[7][gen]).all()      # (the failed attempt's iterations are counted on top of the cold solve's:
