@@ -334,41 +334,11 @@ GCS_HD Red3 wg_reduce(Red3 v, double *red, int &phase)
 #endif
 }
 
-// FACET-PARALLEL SUMS.  Several task kinds are `count` outputs that each sum K terms over the `len` facet rows of a unit (Hessian
-// entries, G'kappa): as one task per output the loop over the rows is a dependent chain of `len` LDS round trips -- the longest pole of
-// its region (profiles/r04: the wavefront of the y-row tasks reaches the G'kappa region's barrier 800 ticks after everyone else).  Here
-// an output gets an aligned group of 8 lanes, lane l of the group takes rows l, l + 8, ..., the group adds up with three DPP row shifts
-// (lane 7 of the group ends up with the sum: a row of 16 lanes holds two groups) and that lane stores.  term(o, j, v) adds row j's terms
-// of output o into v[K]; store(o, v) is called once per output.  start: first thread of the kind (Place).  Host build: plain loops.
-template <int K, class TERM, class STORE>
-GCS_HD void wg_fsum(int count, int len, int start, TERM &&term, STORE &&store)
-{
-#if WG_DEVICE
-    for (int t = (wg_tid() - start) & (WG_THREADS - 1), t_end = count * 8; t < t_end; t += WG_THREADS) {
-        const int o = t >> 3, l = t & 7;
-        double v[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = 0.0;
-        for (int j = l; j < len; j += 8) term(o, j, v);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            v[k] += dpp_row_shr<1>(v[k], 0.0);
-            v[k] += dpp_row_shr<2>(v[k], 0.0);
-            v[k] += dpp_row_shr<4>(v[k], 0.0);
-        }
-        if (l == 7) store(o, v);
-    }
-#else
-    (void)start;
-    WG_FOR(o, count) {
-        double v[K];
-        for (int k = 0; k < K; ++k) v[k] = 0.0;
-        for (int j = 0; j < len; ++j) term(o, j, v);
-        store(o, v);
-    }
-#endif
-}
-
+// (Round 4, measured and rejected: FACET-PARALLEL SUMS -- the task kinds that sum over the facet rows of a unit (Hessian entries, G'kappa)
+// with an aligned group of 8 lanes per output, lane l taking rows l, l + 8, ..., three DPP row shifts, the last lane storing.  The barrier-
+// arrival probes of the timing build show the wavefronts of those kinds arriving last in their regions on benchmark4's heaviest vertex
+// (7 facets, degree 8-10), yet the launch got slower, 9 900 -> 9 640 it/s: most vertices have 4-5 facets, where the loop is one batch of
+// loads anyway, and the wider kinds need a second pass over the 512 threads on the heavy ones.  profiles/r04/README.md.)
 // t = r (r + 1) / 2 + c with 0 <= c <= r  ->  (r, c), without a loop (exact for the sizes used here, t < 2^20)
 GCS_HD void tri_decode(int t, int &r, int &c)
 {
@@ -1122,8 +1092,7 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // back to back: with the K_yy tasks right behind the K entries the second wavefront was this region's critical path,
         // 3 900 cycles; measured by duplicating one kind at a time)
         Place pla;
-        // (generic instantiation: the three kinds are facet-parallel sums, 8 lanes per output)
-        const int sK_ = pla.at(BOX ? U * 2 * N : U * 2 * NS * 8), sKy_ = BOX ? 0 : pla.at(U * 2 * N * 8), sKyy_ = pla.at(U * 8);
+        const int sK_ = pla.at(BOX ? U * 2 * N : U * 2 * NS), sKy_ = BOX ? 0 : pla.at(U * 2 * N), sKyy_ = pla.at(U);
         (void)sKy_;
         if constexpr (BOX) {
             // structured forms: one task per (unit, half, coordinate k) -- the diagonal entries of K_h and X_h and the k-th entries
@@ -1146,77 +1115,69 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
                 un[W::XY + ik] = Db[i * m + k] * bp + Db[i * m + k + N] * bn;
             }
         } else {
-            auto dec_k = [&](int t, int &u, int &i, int &k, int &l) {
-                u = t / (2 * NS); const int q = t - u * (2 * NS); i = q / NS; const int pq = q - i * NS;
+            WG_FOR_AT(t, U * 2 * NS, sK_) {          // entries of K_i and X_i (packed lower, both halves)
+                const int u = t / (2 * NS), q = t - u * (2 * NS), i = q / NS, pq = q - i * NS;
+                double *un = UN(u);
+                double *K = un + W::K, *X = un + W::X;
+                const double *Da = un + oR1, *Db = Da + m2;
+                const bool blk = u > 0, out = blk && side_of(u);
+                int k, l;
                 if constexpr (N == 2) { k = pq > 0; l = pq > 1; }      // packed lower index of a 2 x 2 block: (0,0) (1,0) (1,1)
                 else tri_decode(pq, k, l);
-            };
-            wg_fsum<2>(U * 2 * NS, m, sK_,          // entries of K_i and X_i (packed lower, both halves)
-                [&](int t, int j, double (&v)[2]) {
-                    int u, i, k, l; dec_k(t, u, i, k, l);
-                    const double *Da = UN(u) + oR1, *Db = Da + m2;
+                double sk = 0, sx = 0;
+    #pragma unroll 4
+                for (int j = 0; j < m; ++j) {
                     const double aa = A[j * N + k] * A[j * N + l];
-                    v[0] += (Da[i * m + j] + Db[i * m + j]) * aa;
-                    v[1] += Db[i * m + j] * aa;
-                },
-                [&](int t, const double (&v)[2]) {
-                    int u, i, k, l; dec_k(t, u, i, k, l);
-                    double *un = UN(u);
-                    double *K = un + W::K, *X = un + W::X;
-                    const bool blk = u > 0, out = blk && side_of(u);
-                    double sk = v[0];
-                    const double sx = v[1];
-                    if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; if (prox) sk += sm[W::PQ + NX + i * N + k]; }
-                    K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
-                    X[(i * N + k) * NX + i * N + l] = -sx; X[(i * N + l) * NX + i * N + k] = -sx;
-                    const int o = (1 - i) * N;      // the two halves are not coupled directly
-                    K[(i * N + k) * NW + o + l] = 0.0; K[(i * N + l) * NW + o + k] = 0.0;
-                    X[(i * N + k) * NX + o + l] = 0.0; X[(i * N + l) * NX + o + k] = 0.0;
-                });
-            wg_fsum<2>(U * 2 * N, m, sKy_,            // y column of K, y row of X
-                [&](int t, int j, double (&v)[2]) {
-                    const int u = t / (2 * N), ik = t - u * (2 * N), i = ik / N, k = ik - i * N;
-                    const double *Da = UN(u) + oR1, *Db = Da + m2;
-                    const double ba = BC[j] * A[j * N + k];
-                    v[0] -= (Da[i * m + j] + Db[i * m + j]) * ba;
-                    v[1] += Db[i * m + j] * ba;
-                },
-                [&](int t, const double (&v)[2]) {
-                    const int u = t / (2 * N), ik = t - u * (2 * N), i = ik / N, k = ik - i * N;
-                    double *un = UN(u);
-                    const bool blk = u > 0, out = blk && side_of(u);
-                    double sk = v[0];
-                    if (blk && (i == 0 || out)) sk += rho * CEN[k];
-                    if (prox) sk += sm[W::PQ + NX + i * N + k] * CEN[k];
-                    un[W::K + (i * N + k) * NW + 2 * N] = sk; un[W::K + 2 * N * NW + i * N + k] = sk;
-                    un[W::X + 2 * N * NX + i * N + k] = v[1];
-                });
-        }
-        wg_fsum<1>(U, m2, sKyy_,                   // K_yy
-            [&](int u, int j, double (&v)[1]) {
-                const double *Da = UN(u) + oR1, *Db = Da + m2;
-                const double b = BC[j >= m ? j - m : j];
-                v[0] += (Da[j] + Db[j]) * b * b;
-            },
-            [&](int u, const double (&v)[1]) {
+                    sk += (Da[i * m + j] + Db[i * m + j]) * aa;
+                    sx += Db[i * m + j] * aa;
+                }
+                if (k == l) { sk += REG_DELTA; if (blk && (i == 0 || out)) sk += rho; if (prox) sk += sm[W::PQ + NX + i * N + k]; }
+                K[(i * N + k) * NW + i * N + l] = sk; K[(i * N + l) * NW + i * N + k] = sk;
+                X[(i * N + k) * NX + i * N + l] = -sx; X[(i * N + l) * NX + i * N + k] = -sx;
+                const int o = (1 - i) * N;      // the two halves are not coupled directly
+                K[(i * N + k) * NW + o + l] = 0.0; K[(i * N + l) * NW + o + k] = 0.0;
+                X[(i * N + k) * NX + o + l] = 0.0; X[(i * N + l) * NX + o + k] = 0.0;
+            }
+            WG_FOR_AT(t, U * 2 * N, sKy_) {           // y column of K, y row of X
+                const int u = t / (2 * N), ik = t - u * (2 * N), i = ik / N, k = ik - i * N;
                 double *un = UN(u);
+                const double *Da = un + oR1, *Db = Da + m2;
                 const bool blk = u > 0, out = blk && side_of(u);
-                double sk = v[0];
-                const double yy = un[W::P + 2 * N];
-                sk += un[W::LB] * rcp1(yy) + un[W::LB + 1] * rcp1(1.0 - yy) + REG_DELTA;
-                if (blk) {
-                    double cc = 0;
-#pragma unroll
-                    for (int k = 0; k < N; ++k) cc += CEN[k] * CEN[k];
-                    sk += rho * (1.0 + (out ? 2.0 : 1.0) * cc);
+                double sk = 0, sx = 0;
+    #pragma unroll 4
+                for (int j = 0; j < m; ++j) {
+                    const double ba = BC[j] * A[j * N + k];
+                    sk -= (Da[i * m + j] + Db[i * m + j]) * ba;
+                    sx += Db[i * m + j] * ba;
                 }
-                if (prox) {
-                    sk += sm[W::PQ + NX + 2 * N];
+                if (blk && (i == 0 || out)) sk += rho * CEN[k];
+                if (prox) sk += sm[W::PQ + NX + i * N + k] * CEN[k];
+                un[W::K + (i * N + k) * NW + 2 * N] = sk; un[W::K + 2 * N * NW + i * N + k] = sk;
+                un[W::X + 2 * N * NX + i * N + k] = sx;
+            }
+        }
+        WG_FOR_AT(u, U, sKyy_) {                   // K_yy
+            double *un = UN(u);
+            const double *Da = un + oR1, *Db = Da + m2;
+            const bool blk = u > 0, out = blk && side_of(u);
+            double sk = 0;
+#pragma unroll 4
+            for (int j = 0; j < m2; ++j) { const double b = BC[j >= m ? j - m : j]; sk += (Da[j] + Db[j]) * b * b; }
+            const double yy = un[W::P + 2 * N];
+            sk += un[W::LB] * rcp1(yy) + un[W::LB + 1] * rcp1(1.0 - yy) + REG_DELTA;
+            if (blk) {
+                double cc = 0;
 #pragma unroll
-                    for (int k = 0; k < 2 * N; ++k) sk += sm[W::PQ + NX + k] * CEN[k < N ? k : k - N] * CEN[k < N ? k : k - N];
-                }
-                if constexpr (BOX) un[W::KYY] = sk; else un[W::K + 2 * N * NW + 2 * N] = sk;
-            });
+                for (int k = 0; k < N; ++k) cc += CEN[k] * CEN[k];
+                sk += rho * (1.0 + (out ? 2.0 : 1.0) * cc);
+            }
+            if (prox) {
+                sk += sm[W::PQ + NX + 2 * N];
+#pragma unroll
+                for (int k = 0; k < 2 * N; ++k) sk += sm[W::PQ + NX + k] * CEN[k < N ? k : k - N] * CEN[k < N ? k : k - N];
+            }
+            if constexpr (BOX) un[W::KYY] = sk; else un[W::K + 2 * N * NW + 2 * N] = sk;
+        }
         WG_ARRIVE(2);
         WG_SYNC();
         WG_STAMP(2);
@@ -1635,44 +1596,36 @@ GCS_HD void wg_solve_vertex(const WgArgs<T> &a, int v, double rho, double mu_sca
         // G' kappa per unit: own unknowns (GU) and the x part (GX).  One task per (unit, half, coordinate) forms both entries: they
         // run over the same rows (kappa_a and kappa_b of every facet), so one pass over the row arrays serves both
         Place plg;
-        if constexpr (BOX) {
-            WG_FOR_AT(t, U * 2 * N, plg.at(U * 2 * N)) {
-                const int u = t / (2 * N), q = t - u * (2 * N), i = q / N, k = q - i * N;
-                double *un = UN(u);
-                const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
+        WG_FOR_AT(t, U * 2 * N, plg.at(U * 2 * N)) {
+            const int u = t / (2 * N), q = t - u * (2 * N), i = q / N, k = q - i * N;
+            double *un = UN(u);
+            const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
+            double su = 0, sx = 0;
+            if constexpr (BOX) {
                 const int jp = i * m + k, jn = jp + N;
                 const double kbp = (sigmu - eb[jp]) * ib[jp], kbn = (sigmu - eb[jn]) * ib[jn];
-                un[W::GU + q] = ((sigmu - ea[jp]) * ia[jp] - kbp) - ((sigmu - ea[jn]) * ia[jn] - kbn);
-                un[W::GX + q] = kbp - kbn;
-            }
-        } else {
-            wg_fsum<2>(U * 2 * N, m, plg.at(U * 2 * N * 8),      // facet-parallel: 8 lanes per (unit, half, coordinate)
-                [&](int t, int j, double (&v)[2]) {
-                    const int u = t / (2 * N), q = t - u * (2 * N), i = q / N, k = q - i * N;
-                    const double *un = UN(u);
-                    const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
+                su = ((sigmu - ea[jp]) * ia[jp] - kbp) - ((sigmu - ea[jn]) * ia[jn] - kbn);
+                sx = kbp - kbn;
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < m; ++j) {
                     const double kb = (sigmu - eb[i * m + j]) * ib[i * m + j], aj = A[j * N + k];
-                    v[0] += aj * ((sigmu - ea[i * m + j]) * ia[i * m + j] - kb);
-                    v[1] += aj * kb;
-                },
-                [&](int t, const double (&v)[2]) {
-                    const int u = t / (2 * N), q = t - u * (2 * N);
-                    double *un = UN(u);
-                    un[W::GU + q] = v[0];
-                    un[W::GX + q] = v[1];
-                });
+                    su += aj * ((sigmu - ea[i * m + j]) * ia[i * m + j] - kb);
+                    sx += aj * kb;
+                }
+            }
+            un[W::GU + q] = su;
+            un[W::GX + q] = sx;
         }
-        wg_fsum<1>(U, m2, plg.at(U * 8),           // the y entry: all 2m facet rows of the unit, then its two bounds
-            [&](int u, int j, double (&v)[1]) {
-                const double *un = UN(u);
-                const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
-                v[0] += BC[j >= m ? j - m : j] * ((sigmu - eb[j]) * ib[j] - (sigmu - ea[j]) * ia[j]);
-            },
-            [&](int u, const double (&v)[1]) {
-                double *un = UN(u);
-                const double yy = un[W::P + 2 * N];
-                un[W::GU + 2 * N] = v[0] - (sigmu - un[W::KB]) * rcp1(yy) + (sigmu - un[W::KB + 1]) * rcp1(1.0 - yy);
-            });
+        WG_FOR_AT(u, U, plg.at(U)) {
+            double *un = UN(u);
+            const double *ea = un + oR1, *eb = ea + m2, *ia = un + oR2, *ib = ia + m2;
+            double s = 0;
+#pragma unroll 4
+            for (int j = 0; j < m2; ++j) s += BC[j >= m ? j - m : j] * ((sigmu - eb[j]) * ib[j] - (sigmu - ea[j]) * ia[j]);
+            const double yy = un[W::P + 2 * N];
+            un[W::GU + 2 * N] = s - (sigmu - un[W::KB]) * rcp1(yy) + (sigmu - un[W::KB + 1]) * rcp1(1.0 - yy);
+        }
         WG_ARRIVE(16);
         WG_SYNC();
         WG_STAMP(16);
