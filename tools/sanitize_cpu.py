@@ -14,10 +14,10 @@ def step(fn,g,z,m):
     c=g.c; NI=2*g.num_edges
     copy=np.zeros((c,NI)); xv=np.zeros((g.num_vertices,2*g.n)); zv=np.zeros_like(xv); yv=np.zeros(g.num_vertices)
     cnt=np.zeros(2,dtype=np.int32); gen=np.zeros(g.num_vertices,dtype=np.int32)
-    r=getattr(lib,fn)(g.n,g.num_vertices,g.num_edges,NI,p(g.inc_ptr),p(g.inc_edge),p(g.inc_out),p(g.poly_ptr),p(g.poly_A),p(g.poly_b),p(g.interior),g.src,g.dst,p(z),p(m),C.c_double(1.0),C.c_double(1.0),C.c_double(1e-4),C.c_double(1e-9),60,p(copy),p(xv),p(zv),p(yv),p(cnt),p(gen))
+    r=getattr(lib,fn)(g.n,g.num_vertices,g.num_edges,NI,p(g.inc_ptr),p(g.inc_edge),p(g.inc_out),p(g.poly_ptr),p(g.poly_A),p(g.poly_b),p(g.interior),g.src,g.dst,p(z),p(m),C.c_double(1.0),C.c_double(1.0),C.c_double(1e-4),C.c_double(IPM_TOL),60,p(copy),p(xv),p(zv),p(yv),p(cnt),p(gen))
     assert r==0
 graphs=[('benchmark4',load_fixture('benchmark4')[1],'emu_vertex_step'),('benchmark3',load_fixture('benchmark3')[1],'emu_vertex_step'),
-        ('lattice m4',lattice_boxes(9,7,seed=1),'emu_vertex_step_m4'),('lattice n6',lattice_boxes(5,4,n=6,seed=1),'emu_vertex_step'),
+        ('lattice boxes',lattice_boxes(9,7,seed=1),'emu_vertex_step_box'),('lattice n6',lattice_boxes(5,4,n=6,seed=1),'emu_vertex_step'),
         ('star',graph_from_sets(*star_case(24)),'emu_vertex_step')]
 for name,g,fn in graphs:
     o=Oracle(g,ipm_tol=IPM_TOL)
@@ -32,7 +32,7 @@ def wg_step(g, z, m):
     copy = np.zeros((c, NI)); xv = np.zeros((V, 2 * g.n)); zv = np.zeros_like(xv); yv = np.zeros(V)
     cnt = np.zeros(2, dtype=np.int32); gen = np.zeros(V, dtype=np.int32); st = np.zeros(V, dtype=np.int32); it = np.zeros(V, dtype=np.int32)
     r = wg.wg_emu_vertex_step(g.n, V, g.num_edges, NI, p(g.inc_ptr), p(g.inc_edge), p(g.inc_out), p(g.poly_ptr), p(g.poly_A), p(g.poly_b),
-                              p(g.interior), g.src, g.dst, p(z), p(m), C.c_double(1.0), C.c_double(1.0), C.c_double(1e-4), C.c_double(1e-9), 60,
+                              p(g.interior), g.src, g.dst, p(z), p(m), C.c_double(1.0), C.c_double(1.0), C.c_double(1e-4), C.c_double(IPM_TOL), 60,
                               p(copy), p(xv), p(zv), p(yv), p(cnt), p(gen), p(st), p(it))
     assert r == 0 and cnt[0] == 0
 wg_graphs = [('benchmark4', load_fixture('benchmark4')[1], 0), ('lattice n2', lattice_boxes(6, 5, seed=1), 0), ('lattice n3 box', lattice_boxes(4, 3, n=3, seed=1), 1),
@@ -47,7 +47,7 @@ for name, g, box in wg_graphs:
 
 # ---- oracle under the sanitizers
 import oracle.oracle as O
-O._lib=C.CDLL('/tmp/libo_asan.so'); O._lib.oracle_compute_cost.restype=C.c_double
+O._lib=C.CDLL('/tmp/libo_asan.so'); O._lib.oracle_compute_cost.restype=C.c_double; O._lib.oracle_warm_doubles.restype=C.c_longlong
 from gcs_admm_amd.cases import load_fixture
 from gcs_admm_amd.graph import lattice_boxes
 for name in ('benchmark1','benchmark4'):
