@@ -1,0 +1,41 @@
+"""Soak of tests/test_gpu_parity.py::test_random_scenes_fuzz over many seeds: random polygon scenes, random penalty, the vertex step of
+the device against the oracle's from random (unreachable) states.  Prints the distribution of the worst entry per step and counts
+steps above the test's 2e-3 bound (round 3, before a warm solve was barred from the precision-exhausted exit: 5 of 1 920 steps above it,
+worst 6.9e-3).   python tools/fuzz_soak.py [seeds] [program]"""
+import json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+from gcs_admm_amd import IPM_TOL
+from gcs_admm_amd.graph import graph_from_sets
+from gcs_admm_amd.solver import DeviceSolver
+from oracle.oracle import Oracle
+from scale_demo import polygon_scene
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+program = sys.argv[2] if len(sys.argv) > 2 else "auto"
+worst, fails, above = [], 0, []
+for seed in range(n_seeds):
+    rng = np.random.default_rng(100 + seed)
+    As, bs = polygon_scene(5 + seed % 3, seed=seed, m=3 + seed % 5)
+    g = graph_from_sets(As, bs, 2)
+    o = Oracle(g, ipm_tol=IPM_TOL)
+    d = DeviceSolver(g, "f64", device=0, program=program)
+    rho = float([0.25, 1.0, 4.0][seed % 3])
+    d.reset(rho=rho)
+    for it in range(8):
+        if it >= 4:
+            o.zedge += 0.05 * rng.normal(size=o.zedge.shape); o.mu += 0.02 * rng.normal(size=o.mu.shape)
+        d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu.copy_(torch.from_numpy(o.mu))
+        d.vertex_step()
+        fails += int(o.vertex_step(rho, 1.0) != 0)
+        diff = np.abs(d.copy.cpu().numpy() - o.copy)
+        worst.append(float(diff.max()))
+        if diff.max() > 2e-3:
+            above.append((seed, it, float(diff.max())))
+        o.edge_step(1.0)
+    d.close()
+w = np.array(worst)
+print(json.dumps({"program": program, "scenes": n_seeds, "steps": len(w), "oracle_failures": fails, "worst_entry": {"max": float(w.max()), "p99": float(np.quantile(w, 0.99)),
+                  "median": float(np.median(w))}, "steps_above_2e-3": above}))
