@@ -611,11 +611,15 @@ def main(argv=None):
                               "note": "f32 state; the f64 state and the CPU oracle stop at the same iteration (tests/test_gpu_configs.py)"}
     # ---- CPU baseline: the oracle on the host cores, the same iteration window, bounded sample ----
     if not args.no_cpu and not args.loop_only:
-        out["cpu_baseline"] = cpu_baseline(g, args.workload, first, args.warmup, args.steps, seconds=15.0,
-                                           dev=dev if g.num_vertices > 20000 else None, to_stop=args.workload == "benchmark4")
-        out["gpu_over_cpu_same_window"] = its / out["cpu_baseline"]["value"]
-        if "to_stop" in out["cpu_baseline"] and "value_to_stop" in out:
-            out["gpu_over_cpu_to_stop"] = out["value_to_stop"] / out["cpu_baseline"]["to_stop"]["iterations_per_sec"]
+        try:
+            out["cpu_baseline"] = cpu_baseline(g, args.workload, first, args.warmup, args.steps, seconds=15.0,
+                                               dev=dev if g.num_vertices > 20000 else None, to_stop=args.workload == "benchmark4")
+            out["gpu_over_cpu_same_window"] = its / out["cpu_baseline"]["value"]
+            if "to_stop" in out["cpu_baseline"] and "value_to_stop" in out:
+                out["gpu_over_cpu_to_stop"] = out["value_to_stop"] / out["cpu_baseline"]["to_stop"]["iterations_per_sec"]
+        except Exception as exc:      # the checker's build or run failing must not cost the GPU measurement
+            out["cpu_baseline"] = None
+            out["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
     # ---- the other single-GPU configs of BASELINE.json, compact (default line only) ----
     if args.workload == "benchmark4" and not args.loop_only and not args.no_configs:
         out["configs"] = {}
