@@ -437,6 +437,7 @@ def sharded_leg(args, rank, world, local, steps, warmup, out, with_single):
         tm = pdev.enqueue_partitioned_timed(min(steps, 100))
         pcb2 = pdev.read_control()
         ranks_rccl = pdev.comm_count()
+        boundary_waves = pdev.set_overlap(0)      # (reads back the automatic choice: > 0 when this rank has neighbours and runs the wavefront program)
         if world > 1:
             t = torch.tensor([pel, halo], dtype=torch.float64, device="cuda")
             dist.all_reduce(t[:1], op=dist.ReduceOp.MAX); dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
@@ -458,6 +459,8 @@ def sharded_leg(args, rank, world, local, steps, warmup, out, with_single):
                      "communicator": (f"RCCL, {ranks_rccl} rank(s) by ncclCommCount: the all-reduce runs every iteration" if getattr(pdev, "has_comm", False)
                                       else "none (no all-reduce issued)"),
                      "path": "gcsadmm_run_partitioned (C ABI, RCCL on the caller's stream, no host synchronisation)",
+                     "schedule": (f"overlapped: rank 0's {boundary_waves} boundary wavefronts first, halo exchange on a second stream while the interior is solved"
+                                  if boundary_waves > 0 else "serial (no neighbours: nothing to overlap)"),
                      "rank0_stage_share": {"vertex_step": tm["vertex_ms"] / tot, "halo_exchange": tm["halo_ms"] / tot,
                                            "edge_step": tm["edge_ms"] / tot, "all_reduce_and_control": tm["reduce_ms"] / tot,
                                            "source": "HIP events around every stage on the launch stream, replay of the window on rank 0"},

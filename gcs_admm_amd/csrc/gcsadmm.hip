@@ -9,7 +9,8 @@
 //                        workgroup to finish also does the final reduction and the control step (one launch per edge step)
 //   finalize_kernel / control_kernel   deterministic final reduction; residuals, rho adaptation, stop test,
 //                        trace record (admm_solver_v3.py:697-733): the separate steps of the partitioned loop
-//   halo_pack / halo_unpack_kernel     messages of the cut edges' copies between vertex partitions (RCCL)
+//   halo_pack / halo_unpack_kernel     messages of the cut edges' copies between vertex partitions (RCCL); in the overlapped
+//                        partitioned loop they and the transfer run on a second stream while the interior wavefronts are solved
 //   cost_kernel<T>       GCS_utils.py:184-211
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -248,13 +249,15 @@ __global__ __launch_bounds__(EDGE_BLOCK) void edge_kernel(EdgeArgs<T> a, gcsadmm
 // iterations the units (wavefronts / workgroups) are re-ordered by the Newton iterations of their last launch, descending: a
 // counting sort by one workgroup.  The order among equal counts is arbitrary (atomics); it affects scheduling only, never results.
 constexpr int REORDER_BINS = 64, REORDER_THREADS = 1024, REORDER_EVERY = 8, REORDER_MIN_UNITS = 512;
-__global__ __launch_bounds__(REORDER_THREADS) void reorder_kernel(int n, const int *iters, int *order, const gcsadmm_control_block *cb)
+// ids (may be null): the units to order are ids[0 .. n) instead of 0 .. n (the boundary / interior subsets of a partition's overlapped loop)
+__global__ __launch_bounds__(REORDER_THREADS) void reorder_kernel(int n, const int *iters, int *order, const gcsadmm_control_block *cb, const int *ids = nullptr)
 {
     if (cb->status != GCSADMM_RUNNING) return;
     __shared__ int cnt[REORDER_BINS], off[REORDER_BINS];
     if (threadIdx.x < REORDER_BINS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    auto key = [&](int i) { const int k = iters[i]; return k < 0 ? 0 : (k >= REORDER_BINS ? REORDER_BINS - 1 : k); };
+    auto unit = [&](int i) { return ids ? ids[i] : i; };
+    auto key = [&](int i) { const int k = iters[unit(i)]; return k < 0 ? 0 : (k >= REORDER_BINS ? REORDER_BINS - 1 : k); };
     for (int i = threadIdx.x; i < n; i += REORDER_THREADS) atomicAdd(&cnt[key(i)], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(REORDER_THREADS) void reorder_kernel(int n, const i
         for (int b = REORDER_BINS - 1; b >= 0; --b) { off[b] = run; run += cnt[b]; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += REORDER_THREADS) order[atomicAdd(&off[key(i)], 1)] = i;
+    for (int i = threadIdx.x; i < n; i += REORDER_THREADS) order[atomicAdd(&off[key(i)], 1)] = unit(i);
 }
 
 // fixed-order reduction of the per-workgroup partials -> sums[5]
@@ -380,6 +383,15 @@ struct gcsadmm_handle_s {
     // slowest-first dispatch (reorder_kernel): per wavefront / per workgroup-program vertex, last Newton iteration count and launch order
     int *d_wave_iters = nullptr, *d_wave_order = nullptr, *d_wg_iters = nullptr, *d_wg_order = nullptr;
     int vertex_steps = 0;     // vertex steps enqueued since the last reset
+    // overlapped partitioned loop (boundary vertices first, the halo exchange behind them while the interior is solved):
+    // host copies of the wavefront packing (which wavefront holds which vertex) and of the column -> vertex map, the split of the
+    // wavefronts into boundary (holding a vertex with a cut edge) and interior, a second stream for the exchange and two events
+    std::vector<int> h_wave_slot_ptr, h_wave_vtx, col_vertex;
+    int overlap_mode = 0;     // gcsadmm_set_overlap: 0 automatic, 1 forced (tests: works without peers), 2 off
+    int n_wave_b = 0;         // boundary wavefronts (0: no split)
+    int *d_split_ids = nullptr, *d_split_order = nullptr;    // [n_waves] static ids / launch order: boundary wavefronts first, then interior
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
 };
 
 // ---- RCCL, bound at run time ----
@@ -502,8 +514,24 @@ static WgLaunchDesc make_wg_desc(gcsadmm_handle h, const gcsadmm_state *st, bool
     return d;
 }
 
-template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s)
+// part: -1 the whole vertex step; 0 / 1 the boundary / interior wavefronts of the overlapped partitioned loop (handles whose generic
+// vertices are all on the wavefront program; the closed-form vertices ride with the boundary part; the reorder step follows part 1)
+template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s, int part = -1)
 {
+    if (part >= 0) {
+        VertexLaunchDesc d = make_launch_desc(h, st);
+        d.wave_order = h->d_split_order + (part ? h->n_wave_b : 0);
+        d.n_waves = part ? h->n_waves - h->n_wave_b : h->n_wave_b;
+        if (part) d.n_special = 0;
+        launch_vertex_dim<2, T>(d, s);
+        if (part == 1 && ++h->vertex_steps % REORDER_EVERY == 0 && h->d_wave_iters) {      // slowest first, inside each part
+            hipLaunchKernelGGL(reorder_kernel, dim3(1), dim3(REORDER_THREADS), 0, s, h->n_wave_b, h->d_wave_iters, h->d_split_order, h->d_cb, h->d_split_ids);
+            hipLaunchKernelGGL(reorder_kernel, dim3(1), dim3(REORDER_THREADS), 0, s, h->n_waves - h->n_wave_b, h->d_wave_iters,
+                               h->d_split_order + h->n_wave_b, h->d_cb, h->d_split_ids + h->n_wave_b);
+        }
+        HIPCHK(h, hipGetLastError());
+        return GCSADMM_OK;
+    }
     const bool special_on_wave = h->n_waves > 0;
     if (h->n_waves > 0) {
         VertexLaunchDesc d = make_launch_desc(h, st);
@@ -604,6 +632,49 @@ static gcsadmm_status halo_validate(gcsadmm_handle h, int rank, int world, const
     return GCSADMM_OK;
 }
 
+static void overlap_free(gcsadmm_handle h)
+{
+    for (void **p : {(void **)&h->d_split_ids, (void **)&h->d_split_order})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (h->ev_boundary) { (void)hipEventDestroy(h->ev_boundary); h->ev_boundary = nullptr; }
+    if (h->ev_halo) { (void)hipEventDestroy(h->ev_halo); h->ev_halo = nullptr; }
+    if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+    h->n_wave_b = 0;
+}
+
+// The split of the wavefronts for the overlapped loop: boundary = holds a vertex one of whose columns is sent to a neighbour.  Only for
+// handles whose generic vertices all run the wavefront program (config 4's strips); mode 1 (tests) splits even without neighbours --
+// the first quarter of the wavefronts plays the boundary -- so that the two launches, the second stream and the events can be
+// exercised on one GPU.  Leaves n_wave_b = 0 when there is nothing to split.
+static gcsadmm_status overlap_setup(gcsadmm_handle h, const gcsadmm_halo_desc *hd)
+{
+    overlap_free(h);
+    if (h->overlap_mode == 2 || h->n_waves < 2 || h->n_wg > 0) return GCSADMM_OK;
+    const int n_send = (hd && hd->num_peers > 0) ? hd->send_ptr[hd->num_peers] : 0;
+    if (n_send == 0 && h->overlap_mode != 1) return GCSADMM_OK;
+    std::vector<char> vb((size_t)std::max(h->V, 1), 0);
+    for (int j = 0; j < n_send; ++j) {
+        const int v = h->col_vertex[hd->send_cols[j]];
+        if (v >= 0) vb[v] = 1;
+    }
+    std::vector<int> ids_b, ids_i;
+    for (int w = 0; w < h->n_waves; ++w) {
+        bool b = (n_send == 0) && w < std::max(1, h->n_waves / 4);
+        for (int q = h->h_wave_slot_ptr[w]; q < h->h_wave_slot_ptr[w + 1] && !b; ++q) b = vb[h->h_wave_vtx[q]] != 0;
+        (b ? ids_b : ids_i).push_back(w);
+    }
+    if (ids_b.empty() || ids_i.empty()) return GCSADMM_OK;      // nothing to overlap with
+    h->n_wave_b = (int)ids_b.size();
+    ids_b.insert(ids_b.end(), ids_i.begin(), ids_i.end());
+    HIPCHK(h, upload(&h->d_split_ids, ids_b.data(), ids_b.size()));
+    HIPCHK(h, upload(&h->d_split_order, ids_b.data(), ids_b.size()));
+    if (!h->d_wave_iters) HIPCHK(h, upload(&h->d_wave_iters, (const int *)nullptr, (size_t)h->n_waves));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_boundary, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
+    return GCSADMM_OK;
+}
+
 static void halo_free(gcsadmm_handle h)
 {
     for (void **p : {(void **)&h->d_send_cols, (void **)&h->d_send_base, (void **)&h->d_send_stride, (void **)&h->d_recv_cols, (void **)&h->d_recv_base,
@@ -691,6 +762,7 @@ void gcsadmm_destroy(gcsadmm_handle h)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     halo_free(h);
+    overlap_free(h);
     if (h->comm && rccl().ok()) (void)rccl().CommDestroy((ncclComm_t)h->comm);
     for (auto ev : h->events) (void)hipEventDestroy(ev);
     delete h;
@@ -888,6 +960,11 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     for (int v = 0; v < V; ++v)
         for (int k = g->inc_ptr[v]; k < g->inc_ptr[v + 1]; ++k)
             h->col_owned[h->edge_major ? g->inc_edge[k] + (g->inc_out[k] ? 0 : E) : k] = 1;
+    h->col_vertex.assign((size_t)std::max<int64_t>(g->num_incidences, 1), -1);
+    for (int v = 0; v < V; ++v)
+        for (int k = g->inc_ptr[v]; k < g->inc_ptr[v + 1]; ++k)
+            h->col_vertex[h->edge_major ? g->inc_edge[k] + (g->inc_out[k] ? 0 : E) : k] = v;
+    h->h_wave_slot_ptr = wave_slot_ptr; h->h_wave_vtx = wave_vtx;
     h->dtype = g->state_dtype; h->device = g->device;
     h->n_waves = n_waves; h->n_special = (int)special_vtx.size();
     h->slots_cap = std::max(1, max_slots_used);
@@ -990,6 +1067,7 @@ gcsadmm_status gcsadmm_reset(gcsadmm_handle h, const gcsadmm_params *p, void *st
     // a new run starts without warm-start records (runs from the same state are then identical, whatever ran before)
     if (h->warm_doubles > 0) HIPCHK(h, hipMemsetAsync(h->d_warm, 0, h->warm_doubles * sizeof(double), (hipStream_t)stream));
     h->vertex_steps = 0;
+    if (h->d_split_order) HIPCHK(h, hipMemcpyAsync(h->d_split_order, h->d_split_ids, sizeof(int) * (size_t)h->n_waves, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     for (auto po : {std::make_pair(h->d_wave_order, h->n_waves), std::make_pair(h->d_wg_order, h->n_wg)})
         if (po.first) {
             std::vector<int> iota(po.second);
@@ -1089,7 +1167,7 @@ gcsadmm_status gcsadmm_attach_comm(gcsadmm_handle h, int32_t rank, int32_t world
         }
         h->comm = comm;
     }
-    return GCSADMM_OK;
+    return overlap_setup(h, halo);
 }
 
 gcsadmm_status gcsadmm_halo_pack(gcsadmm_handle h, const gcsadmm_state *st, void *stream)
@@ -1131,6 +1209,38 @@ static gcsadmm_status run_partitioned_loop(gcsadmm_handle h, const gcsadmm_state
     const gcsadmm_params &pp = h->params;
     const ControlParams cp{pp.tau_incr, pp.tau_decr, pp.nu, pp.eps_abs, pp.eps_rel, h->nx, h->nmu, pp.it_rho_limit, pp.max_it};
     if (!h->comm && h->world > 1) { h->err = "gcsadmm_run_partitioned needs a communicator (gcsadmm_attach_comm with an id)"; return GCSADMM_ERR_BAD_ARG; }
+    // OVERLAPPED form (not for the stage-timed twin, whose events want one stream): the boundary wavefronts first, then --
+    // on a second stream, behind an event -- pack, grouped send / recv and unpack of the halo WHILE the interior wavefronts are solved
+    // on the caller's stream; the edge step waits for both.  Same kernels, same numbers: the split only changes what runs when.
+    //   s : boundary launch -> [ev_boundary] -> interior launch -> wait [ev_halo] -> edge step -> all-reduce -> control
+    //   sc:                   wait [ev_boundary] -> pack -> send / recv -> unpack -> [ev_halo]
+    // (RCCL orders the operations of one communicator across streams itself; every rank issues them in the same order.)
+    const bool overlap = !ev && h->n_wave_b > 0 && h->overlap_mode != 2;
+    for (int i = 0; i < k && overlap; ++i) {
+        gcsadmm_status r;
+        const bool f64 = h->dtype == GCSADMM_F64;
+        if ((r = f64 ? launch_vertex<double>(h, st, s, 0) : launch_vertex<float>(h, st, s, 0)) != GCSADMM_OK) return r;
+        HIPCHK(h, hipEventRecord(h->ev_boundary, s));
+        HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_boundary, 0));
+        if ((r = gcsadmm_halo_exchange(h, st, (void *)h->comm_stream)) != GCSADMM_OK) return r;
+        HIPCHK(h, hipEventRecord(h->ev_halo, h->comm_stream));
+        if ((r = f64 ? launch_vertex<double>(h, st, s, 1) : launch_vertex<float>(h, st, s, 1)) != GCSADMM_OK) return r;
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_halo, 0));
+        r = f64 ? launch_edge<double>(h, st, h->d_sums6, s, false, nullptr, true) : launch_edge<float>(h, st, h->d_sums6, s, false, nullptr, true);
+        if (r != GCSADMM_OK) return r;
+        const double *reduced = h->d_sums6;
+        if (h->comm) {
+            NCCLCHK(h, rccl().AllReduce(h->d_sums6, h->d_sums6 + 6, 6, ncclFloat64, ncclSum, (ncclComm_t)h->comm, s));
+            reduced = h->d_sums6 + 6;
+        }
+        hipLaunchKernelGGL(control_kernel, dim3(1), dim3(1), 0, s, h->d_cb, reduced, cp, h->d_counters, trace_dev, true);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (overlap) {      // the caller's stream is the one the caller synchronises: nothing of this call may still run on the other
+        HIPCHK(h, hipEventRecord(h->ev_halo, h->comm_stream));
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_halo, 0));
+        return GCSADMM_OK;
+    }
     for (int i = 0; i < k; ++i) {
         gcsadmm_status r;
         if (ev) HIPCHK(h, hipEventRecord(ev[6 * i + 0], s));
@@ -1188,6 +1298,25 @@ gcsadmm_status gcsadmm_run_partitioned_timed(gcsadmm_handle h, const gcsadmm_sta
     }
     *vertex_ms = (float)acc[0]; *halo_ms = (float)acc[1]; *edge_ms = (float)acc[2]; *reduce_ms = (float)acc[3];
     return GCSADMM_OK;
+}
+
+gcsadmm_status gcsadmm_set_overlap(gcsadmm_handle h, int32_t mode, int32_t *boundary_units)
+{
+    if (!h || mode < 0 || mode > 2) return GCSADMM_ERR_BAD_ARG;
+    if (boundary_units) *boundary_units = 0;
+    if (!h->d_sums6) { h->err = "gcsadmm_attach_comm has not been called"; return GCSADMM_ERR_BAD_ARG; }
+    USE_DEVICE(h);
+    h->overlap_mode = mode;
+    // the split is derived from the halo lists uploaded at attach: rebuild them as a descriptor of host arrays
+    std::vector<int> send_cols((size_t)std::max(h->n_send, 1)), ptr(h->peers.size() + 1, 0);
+    if (h->n_send > 0) HIPCHK(h, hipMemcpy(send_cols.data(), h->d_send_cols, sizeof(int) * (size_t)h->n_send, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < h->peers.size(); ++p) ptr[p + 1] = ptr[p] + h->peer_cnt[p];
+    gcsadmm_halo_desc hd{};
+    hd.num_peers = (int)h->peers.size(); hd.peer_rank = h->peers.data(); hd.send_ptr = ptr.data(); hd.send_cols = send_cols.data();
+    hd.recv_ptr = ptr.data(); hd.recv_cols = send_cols.data();
+    const gcsadmm_status r = overlap_setup(h, &hd);
+    if (boundary_units) *boundary_units = h->n_wave_b;
+    return r;
 }
 
 gcsadmm_status gcsadmm_comm_count(gcsadmm_handle h, int32_t *count)

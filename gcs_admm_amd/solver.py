@@ -28,7 +28,7 @@ EXPORTS = ["gcsadmm_create", "gcsadmm_destroy", "gcsadmm_last_error", "gcsadmm_r
            "gcsadmm_cost", "gcsadmm_query", "gcsadmm_unit_iterations", "gcsadmm_vertex_prox",
            # vertex partitions across GPUs (RCCL)
            "gcsadmm_comm_unique_id", "gcsadmm_check_halo", "gcsadmm_attach_comm", "gcsadmm_run_partitioned", "gcsadmm_halo_pack", "gcsadmm_halo_unpack",
-           "gcsadmm_halo_exchange", "gcsadmm_halo_buffers", "gcsadmm_run_partitioned_timed", "gcsadmm_comm_count",
+           "gcsadmm_halo_exchange", "gcsadmm_halo_buffers", "gcsadmm_run_partitioned_timed", "gcsadmm_comm_count", "gcsadmm_set_overlap",
            # graph construction at scale (gcs_admm_amd/scene.py)
            "gcsadmm_polytope_last_error", "gcsadmm_polytope_centers", "gcsadmm_polytope_bounds", "gcsadmm_polytope_overlaps"]
 
@@ -321,6 +321,14 @@ class DeviceSolver:
                                                                self._stream(), C.byref(v), C.byref(hl), C.byref(e), C.byref(r)),
                         "gcsadmm_run_partitioned_timed")
         return dict(vertex_ms=v.value, halo_ms=hl.value, edge_ms=e.value, reduce_ms=r.value)
+
+    def set_overlap(self, mode: int = 0) -> int:
+        """Schedule of the partitioned loop (include/gcsadmm.h gcsadmm_set_overlap): 0 automatic (overlapped when the partition has
+        neighbours), 1 overlapped even without neighbours (tests), 2 serial.  Returns the number of boundary wavefronts (0: serial)."""
+        n = C.c_int32(0)
+        with self.torch.cuda.device(self.device):
+            self._check(self.lib.gcsadmm_set_overlap(self.h, int(mode), C.byref(n)), "gcsadmm_set_overlap")
+        return n.value
 
     def comm_count(self) -> int:
         """ranks of the attached RCCL communicator as RCCL reports them (0: none attached)"""

@@ -255,6 +255,33 @@ def test_partitioned_loop_behind_the_abi_single_rank(torch_gpu):
 
 
 @pytest.mark.parametrize("columns", ["incidence", "edge"])
+def test_overlapped_partitioned_loop_equals_serial(torch_gpu, columns):
+    """The overlapped schedule of gcsadmm_run_partitioned (boundary wavefronts first, the halo exchange on a second stream behind an
+    event while the interior wavefronts are solved, the edge step waiting for both) against the serial one and against the plain
+    loop: the same bits.  One rank (a real one-rank RCCL communicator), so the split is forced: the first quarter of the wavefronts
+    plays the boundary -- the two launches, their slowest-first re-ordering inside each part (every eighth step), the second stream
+    and the two events are what is exercised; the exchange itself moves nothing here."""
+    from gcs_admm_amd.solver import DeviceSolver
+    g = lattice_boxes(40, 40, seed=3)
+    steps = 40
+    out = {}
+    for mode in ("plain", 2, 1):
+        d = DeviceSolver(g, "f32", device=0, program="wavefront", columns=columns)
+        if mode != "plain":
+            d.attach_comm(0, 1, d.unique_id(), {}, {})
+            nb = d.set_overlap(mode)
+            assert (nb > 0) == (mode == 1) and nb < d.query()["num_waves"]
+        d.reset(max_it=steps + 10)
+        (d.enqueue if mode == "plain" else d.enqueue_partitioned)(steps)
+        cb = d.read_control()
+        assert cb.it == steps + 1 and cb.status == -1 and cb.inner_failures == 0
+        out[mode] = [t.cpu().numpy().copy() for t in (d.trace[:steps], d.copy, d.mu, d.zedge, d.xv, d.zv, d.yv)]
+        d.close()
+    for a, b, c in zip(out["plain"], out[2], out[1]):
+        assert np.array_equal(a, b) and np.array_equal(b, c)
+
+
+@pytest.mark.parametrize("columns", ["incidence", "edge"])
 def test_halo_pack_unpack_two_handles(torch_gpu, columns):
     """the pack / unpack kernels and halo lists of the C ABI with the transfer done by hand: two partitions of one lattice
     as two handles on this GPU; packed send buffers are copied device-to-device into the peer's receive buffer (what
