@@ -426,6 +426,20 @@ def sharded_leg(args, rank, world, local, steps, warmup, out, with_single):
         if ok and float(flag.item()) == 0.0:
             block = {"error": "another rank failed to set up its partition"}
         ok = float(flag.item())
+    serial_rate = None
+    if ok and world > 1:
+        # the SERIAL schedule first (vertex step, exchange, edge step on one stream), and its rate into the line at once: should the
+        # overlapped schedule -- two streams, never run with real neighbours before -- stall, the watchdog still prints a measured value
+        pdev.set_overlap(2)
+        sel_ = time_window(pdev, pfirst, warmup, steps, enqueue=pdev.enqueue_partitioned, barrier=dist.barrier)
+        t = torch.tensor([sel_], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        serial_rate = steps / float(t.item())
+        if rank == 0:
+            out.update({"value": serial_rate, "ms_per_step": 1e3 * float(t.item()) / steps, "rccl_ranks": pdev.comm_count(),
+                        "config": {"workload": "s100k", "window": {"first_iteration": pfirst + warmup + 1, "last_iteration": pfirst + warmup + steps},
+                                   "parallelism": f"vertex partition: {world} row strips; SERIAL schedule (the overlapped one did not complete)"}})
+        pdev.set_overlap(0)
     if ok:
         pel = time_window(pdev, pfirst, warmup, steps, enqueue=pdev.enqueue_partitioned, barrier=(dist.barrier if world > 1 else None))
         pcb = pdev.read_control()
@@ -461,6 +475,7 @@ def sharded_leg(args, rank, world, local, steps, warmup, out, with_single):
                      "path": "gcsadmm_run_partitioned (C ABI, RCCL on the caller's stream, no host synchronisation)",
                      "schedule": (f"overlapped: rank 0's {boundary_waves} boundary wavefronts first, halo exchange on a second stream while the interior is solved"
                                   if boundary_waves > 0 else "serial (no neighbours: nothing to overlap)"),
+                     "serial_schedule_iterations_per_sec": serial_rate,
                      "rank0_stage_share": {"vertex_step": tm["vertex_ms"] / tot, "halo_exchange": tm["halo_ms"] / tot,
                                            "edge_step": tm["edge_ms"] / tot, "all_reduce_and_control": tm["reduce_ms"] / tot,
                                            "source": "HIP events around every stage on the launch stream, replay of the window on rank 0"},
