@@ -515,20 +515,18 @@ static WgLaunchDesc make_wg_desc(gcsadmm_handle h, const gcsadmm_state *st, bool
 }
 
 // part: -1 the whole vertex step; 0 / 1 the boundary / interior wavefronts of the overlapped partitioned loop (handles whose generic
-// vertices are all on the wavefront program; the closed-form vertices ride with the boundary part; the reorder step follows part 1)
-template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s, int part = -1)
+// vertices are all on the wavefront program; the closed-form vertices ride with the boundary part)
+template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s, int part = -1, bool reorder = false)
 {
     if (part >= 0) {
         VertexLaunchDesc d = make_launch_desc(h, st);
-        d.wave_order = h->d_split_order + (part ? h->n_wave_b : 0);
-        d.n_waves = part ? h->n_waves - h->n_wave_b : h->n_wave_b;
+        const int off = part ? h->n_wave_b : 0, cnt = part ? h->n_waves - h->n_wave_b : h->n_wave_b;
+        d.wave_order = h->d_split_order + off;
+        d.n_waves = cnt;
         if (part) d.n_special = 0;
         launch_vertex_dim<2, T>(d, s);
-        if (part == 1 && ++h->vertex_steps % REORDER_EVERY == 0 && h->d_wave_iters) {      // slowest first, inside each part
-            hipLaunchKernelGGL(reorder_kernel, dim3(1), dim3(REORDER_THREADS), 0, s, h->n_wave_b, h->d_wave_iters, h->d_split_order, h->d_cb, h->d_split_ids);
-            hipLaunchKernelGGL(reorder_kernel, dim3(1), dim3(REORDER_THREADS), 0, s, h->n_waves - h->n_wave_b, h->d_wave_iters,
-                               h->d_split_order + h->n_wave_b, h->d_cb, h->d_split_ids + h->n_wave_b);
-        }
+        if (reorder && h->d_wave_iters)      // slowest first inside the part, on the part's own stream (its next launch reads the order)
+            hipLaunchKernelGGL(reorder_kernel, dim3(1), dim3(REORDER_THREADS), 0, s, cnt, h->d_wave_iters, h->d_split_order + off, h->d_cb, h->d_split_ids + off);
         HIPCHK(h, hipGetLastError());
         return GCSADMM_OK;
     }
@@ -1209,22 +1207,26 @@ static gcsadmm_status run_partitioned_loop(gcsadmm_handle h, const gcsadmm_state
     const gcsadmm_params &pp = h->params;
     const ControlParams cp{pp.tau_incr, pp.tau_decr, pp.nu, pp.eps_abs, pp.eps_rel, h->nx, h->nmu, pp.it_rho_limit, pp.max_it};
     if (!h->comm && h->world > 1) { h->err = "gcsadmm_run_partitioned needs a communicator (gcsadmm_attach_comm with an id)"; return GCSADMM_ERR_BAD_ARG; }
-    // OVERLAPPED form (not for the stage-timed twin, whose events want one stream): the boundary wavefronts first, then --
-    // on a second stream, behind an event -- pack, grouped send / recv and unpack of the halo WHILE the interior wavefronts are solved
-    // on the caller's stream; the edge step waits for both.  Same kernels, same numbers: the split only changes what runs when.
-    //   s : boundary launch -> [ev_boundary] -> interior launch -> wait [ev_halo] -> edge step -> all-reduce -> control
-    //   sc:                   wait [ev_boundary] -> pack -> send / recv -> unpack -> [ev_halo]
-    // (RCCL orders the operations of one communicator across streams itself; every rank issues them in the same order.)
+    // OVERLAPPED form (not for the stage-timed twin, whose events want one stream): the wavefronts that hold a vertex with a
+    // cut edge are launched FIRST and on a second stream, with pack, grouped send / recv and unpack of the halo behind them; the interior
+    // wavefronts are launched on the caller's stream at the same time, and the edge step waits for both.  Same kernels, same numbers: the
+    // split only changes what runs when.
+    //   s : [ev_boundary = previous iteration done] -> interior launch -> wait [ev_halo] -> edge step -> all-reduce -> control
+    //   sc: wait [ev_boundary] -> boundary launch (+ closed-form vertices) -> pack -> send / recv -> unpack -> [ev_halo]
+    // (The two launches must be CONCURRENT: one after the other on one stream each waits for its own slowest wavefront -- measured on a
+    // strip of 12.6 k vertices, 348 -> 509 us per iteration.  RCCL orders the operations of one communicator across streams itself;
+    // every rank issues them in the same order.)
     const bool overlap = !ev && h->n_wave_b > 0 && h->overlap_mode != 2;
     for (int i = 0; i < k && overlap; ++i) {
         gcsadmm_status r;
         const bool f64 = h->dtype == GCSADMM_F64;
-        if ((r = f64 ? launch_vertex<double>(h, st, s, 0) : launch_vertex<float>(h, st, s, 0)) != GCSADMM_OK) return r;
+        const bool reorder = ++h->vertex_steps % REORDER_EVERY == 0;
         HIPCHK(h, hipEventRecord(h->ev_boundary, s));
         HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_boundary, 0));
+        if ((r = f64 ? launch_vertex<double>(h, st, h->comm_stream, 0, reorder) : launch_vertex<float>(h, st, h->comm_stream, 0, reorder)) != GCSADMM_OK) return r;
         if ((r = gcsadmm_halo_exchange(h, st, (void *)h->comm_stream)) != GCSADMM_OK) return r;
         HIPCHK(h, hipEventRecord(h->ev_halo, h->comm_stream));
-        if ((r = f64 ? launch_vertex<double>(h, st, s, 1) : launch_vertex<float>(h, st, s, 1)) != GCSADMM_OK) return r;
+        if ((r = f64 ? launch_vertex<double>(h, st, s, 1, reorder) : launch_vertex<float>(h, st, s, 1, reorder)) != GCSADMM_OK) return r;
         HIPCHK(h, hipStreamWaitEvent(s, h->ev_halo, 0));
         r = f64 ? launch_edge<double>(h, st, h->d_sums6, s, false, nullptr, true) : launch_edge<float>(h, st, h->d_sums6, s, false, nullptr, true);
         if (r != GCSADMM_OK) return r;

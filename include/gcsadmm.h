@@ -241,8 +241,8 @@ gcsadmm_status gcsadmm_run_partitioned_timed(gcsadmm_handle h, const gcsadmm_sta
                                              float *vertex_ms, float *halo_ms, float *edge_ms, float *reduce_ms);
 
 /* Schedule of gcsadmm_run_partitioned (never its numbers).  The overlapped form ("boundary vertices first") solves the
- * wavefronts that hold a vertex with a cut edge first, then packs, exchanges and unpacks the halo on a second stream WHILE the interior
- * wavefronts are solved on the caller's stream; the edge step waits for both.  It exists for handles whose generic vertices all run the
+ * wavefronts that hold a vertex with a cut edge first and on a second stream, with the pack, exchange and unpack of the halo behind them,
+ * WHILE the interior wavefronts are solved on the caller's stream; the edge step waits for both.  It exists for handles whose generic vertices all run the
  * wavefront program (the strips of a large n = 2 graph).  mode 0 (default, set at attach): overlapped when the partition has neighbours;
  * 1: overlapped even without neighbours (the first quarter of the wavefronts plays the boundary: tests of the schedule on one GPU);
  * 2: the serial form (vertex step, exchange, edge step on one stream).  boundary_units (may be NULL): wavefronts of the boundary part
