@@ -1,7 +1,7 @@
 """Soak of tests/test_gpu_parity.py::test_random_scenes_fuzz over many seeds: random polygon scenes, random penalty, the vertex step of
 the device against the oracle's from random (unreachable) states.  Prints the distribution of the worst entry per step and counts
 steps above the test's 2e-3 bound (round 3, before a warm solve was barred from the precision-exhausted exit: 5 of 1 920 steps above it,
-worst 6.9e-3).   python tools/fuzz_soak.py [seeds] [program]"""
+worst 6.9e-3).   python tools/fuzz_soak.py [seeds] [program] [first seed]"""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +15,9 @@ from scale_demo import polygon_scene
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 program = sys.argv[2] if len(sys.argv) > 2 else "auto"
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 worst, fails, above = [], 0, []
-for seed in range(n_seeds):
+for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(100 + seed)
     As, bs = polygon_scene(5 + seed % 3, seed=seed, m=3 + seed % 5)
     g = graph_from_sets(As, bs, 2)
@@ -37,5 +38,5 @@ for seed in range(n_seeds):
         o.edge_step(1.0)
     d.close()
 w = np.array(worst)
-print(json.dumps({"program": program, "scenes": n_seeds, "steps": len(w), "oracle_failures": fails, "worst_entry": {"max": float(w.max()), "p99": float(np.quantile(w, 0.99)),
+print(json.dumps({"program": program, "first_seed": first, "scenes": n_seeds, "steps": len(w), "oracle_failures": fails, "worst_entry": {"max": float(w.max()), "p99": float(np.quantile(w, 0.99)),
                   "median": float(np.median(w))}, "steps_above_2e-3": above}))
