@@ -101,7 +101,7 @@ void oracle_set_warm_rule(double kappa, double mu_min, double cold_dt) { ws_kapp
 #define WS_MU_MIN ws_mu_min
 #define WS_COLD_DT ws_cold_dt
 /* how the last vertex solve started (tests/warm_rule_sweep.py): 0 no record / rho changed, 1 cold by dT, 2 warm, 3 warm failed then cold */
-static __thread int dbg_kind; static __thread double dbg_dt;      /* how the last vertex solve started: 0 no record / rho changed, 1 cold by dT, 2 warm, 3 warm failed then cold */
+static __thread int dbg_kind; static __thread double dbg_dt, dbg_rd;      /* how the last vertex solve started: 0 no record / rho changed, 1 cold by dT, 2 warm, 3 warm failed then cold */
 #define WS_SAVE 10.0
 #define WS_COLD_REF 1e-4
 long long oracle_warm_doubles(int n, int m, int d)
@@ -722,6 +722,7 @@ restart:
              * bound makes steps of 1e-6 and is several 1e-3 off in that vertex's words); it counts as a failed warm attempt and is
              * repeated cold below.  Cold solves keep the rule (on the fixtures it fires at mu <= 5e-9 only). */
             status = (use_warm && !(mu <= ip->ipm_tol)) ? -7 : 0;
+            dbg_rd = rdmax;
             break;
         }
         if (it == ip->ipm_max_iter) break;
@@ -1031,7 +1032,8 @@ restart:
  * (admm_solver_v3.py:469-540).  targets = zedge - mu_scale * mu.  Returns the number of
  * sub-problems whose inner solver did not converge; ipm_iters_total accumulates iterations. */
 /* diagnostics: when set, oracle_vertex_step records the Newton iteration count of every vertex (-1 = failed) */
-static int *g_iters_out = 0, *g_kind_out = 0; static double *g_dt_out = 0;
+static int *g_iters_out = 0, *g_kind_out = 0; static double *g_dt_out = 0, *g_rd_out = 0;
+void oracle_set_rd_out(double *buf) { g_rd_out = buf; }      /* diagnostic (tools/warm_accuracy_study.py): dual residual at the stop of each vertex's solve */
 void oracle_set_dt_out(double *buf) { g_dt_out = buf; }
 void oracle_set_iters_out(int *buf) { g_iters_out = buf; }
 void oracle_set_kind_out(int *buf) { g_kind_out = buf; }
@@ -1066,6 +1068,7 @@ int oracle_vertex_step(const oracle_graph *G, const double *zedge, const double 
         if (g_iters_out) g_iters_out[v] = r;
         if (g_kind_out) g_kind_out[v] = dbg_kind;
         if (g_dt_out) g_dt_out[v] = dbg_dt;
+        if (g_rd_out) g_rd_out[v] = dbg_rd;
         /* a failed inner solve keeps the vertex's previous copy columns and outputs (the reference's intent at
          * admm_solver_v3.py:524-538; its own branch would raise) and is counted */
         if (r >= 0) {
