@@ -478,14 +478,282 @@ static void *ws_get(size_t bytes)
     if (bytes > ws_cap) { free(ws_buf); ws_cap = bytes + bytes / 2 + 4096; ws_buf = (char *)malloc(ws_cap); }
     return ws_buf;
 }
+#define TW(k, e) T[(k) * d + (e)]
+#define CW(k, e) copy[(k) * d + (e)]
+/* one inequality row of a Newton step: dl = kappa - lambda - (lambda / s) ds, the step bound and the sums of the step-length model */
+#define ROW(sv, lv, dsv, kv, dlout)                                                          \
+    do { double D_ = (lv) / (sv); double dl_ = (kv) - (lv) - D_ * (dsv); (dlout) = dl_;        \
+         if ((dsv) < 0) { amax = fmin(amax, -(sv) / (dsv)); }                                \
+         if (dl_ < 0) { amax = fmin(amax, -(lv) / dl_); }                                    \
+         c1 += (sv) * dl_ + (lv) * (dsv); c2 += (dsv) * dl_; } while (0)
+/* ------------------------------------------------------------------ a terminal that is a REGION
+ * The reference builds 's' / 't' as points (utils.py:12-28), but its vertex update constrains them like any set
+ * (admm_solver_v3.py:415-440 with delta_sv / delta_tv at :450-464).  For v = 's' (v = 't' mirrored, live side = incoming):
+ *   (6) with y_v <= 1 forces y_v = 1 and y_e = 0 on the incoming side, so O_e = 0 there (rows 3 of a bounded set),
+ *   (7) then reads z_v = x_v = sum_{e out} O_e, (6) sum_{e out} y_e = 1;
+ *   rows 1 (A x_i <= b), rows 2 (0 <= 0) and rows 4 (A (x_i - O_{e,i}) <= (1 - y_e) b) are sums of rows 3 of the live blocks and
+ *   of the two equalities -- redundant; the bounds on y_e follow from rows 3 and sum y = 1.
+ * What is left, over the live blocks (O_e in R^{2n}, y_e) and t:
+ *   min  t + sum_e [ eps y_e + rho/2 ( |[O_e]_1 - T1_e|^2 + out_e |[O_e]_2 - T2_e|^2 + (y_e - Ty_e)^2 ) ]
+ *   s.t. A [O_e]_i <= y_e b  (i = 1, 2),   sum_e y_e = 1,   | sum_e ([O_e]_1 - [O_e]_2) | <= t.
+ * (A point collapses this to the simplex projection above.)  Same primal-dual method as the generic vertex (Mehrotra, one step
+ * length, NT scaling of the cone, sigma = (mu_aff / mu)^3, stop on mu), started cold every time from y_e = 1 / L, O_e = y_e (c, c).
+ * The Hessian is block diagonal plus the cone and the equality through F = [I, -I, 0; 0, 0, 1]: blocks are eliminated onto
+ * (du, dnu), n + 1 unknowns.  The HIP twin is csrc/terminal_region.h. */
+static double terminal_extent(int n, int m, const double *A, const double *b_raw, const double *cen)
+{   /* the rule of gcsadmm_create: widest distance from the centre to a facet */
+    double ext = 0;
+    for (int j = 0; j < m; ++j) {
+        double nrm = 0, sl = b_raw[j];
+        for (int k = 0; k < n; ++k) { nrm += A[j * n + k] * A[j * n + k]; sl -= A[j * n + k] * cen[k]; }
+        ext = fmax(ext, fabs(sl) / sqrt(nrm > 0 ? nrm : 1.0));
+    }
+    return ext;
+}
+static int gauss_solve(int N, double *M, int ld, double *x)
+{   /* in place, partial pivoting; x: right-hand side -> solution */
+    for (int c = 0; c < N; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < N; ++r) if (fabs(M[r * ld + c]) > fabs(M[piv * ld + c])) piv = r;
+        if (M[piv * ld + c] == 0.0) return 1;
+        if (piv != c) { for (int k = 0; k < N; ++k) { double tmp = M[c * ld + k]; M[c * ld + k] = M[piv * ld + k]; M[piv * ld + k] = tmp; } double tmp = x[c]; x[c] = x[piv]; x[piv] = tmp; }
+        for (int r = c + 1; r < N; ++r) {
+            const double f = M[r * ld + c] / M[c * ld + c];
+            for (int k = c; k < N; ++k) M[r * ld + k] -= f * M[c * ld + k];
+            x[r] -= f * x[c];
+        }
+    }
+    for (int r = N - 1; r >= 0; --r) { double a = x[r]; for (int k = r + 1; k < N; ++k) a -= M[r * ld + k] * x[k]; x[r] = a / M[r * ld + r]; }
+    return 0;
+}
+static int solve_terminal_region(int n, int m, const double *A, const double *b, const double *cen, int d, int d_in, int is_src,
+                                 const double *T, double rho, const oracle_inner_params *ip, double *copy, double *xv, double *zv, double *yv)
+{
+    const int NW = 2 * n + 1, R = 2 * m, q = n + 1, NF = n + 1, ldq = MAXN + 1;
+    const int lo = is_src ? d_in : 0, hi = is_src ? d : d_in, L = hi - lo;
+    if (L <= 0) return -2;
+    /* per block: p, tg, qd, rhs, hr, dp [NW each] | s, lam, kap, ds, dl [R each] | H [NW*NW] | X [NW*NF] */
+    const size_t per = (size_t)6 * NW + 5 * R + (size_t)NW * NW + (size_t)NW * NF;
+    double *W = (double *)ws_get(per * L * sizeof(double));
+#define TB(e) (W + (size_t)(e) * per)
+#define Tp(e) (TB(e))
+#define Ttg(e) (TB(e) + NW)
+#define Tqd(e) (TB(e) + 2 * NW)
+#define Trhs(e) (TB(e) + 3 * NW)
+#define Thr(e) (TB(e) + 4 * NW)
+#define Tdp(e) (TB(e) + 5 * NW)
+#define Ts(e) (TB(e) + 6 * NW)
+#define Tlam(e) (Ts(e) + R)
+#define Tkap(e) (Ts(e) + 2 * R)
+#define Tds(e) (Ts(e) + 3 * R)
+#define Tdl(e) (Ts(e) + 4 * R)
+#define TH(e) (Ts(e) + 5 * R)
+#define TX(e) (TH(e) + NW * NW)
+    for (int e = 0; e < L; ++e) {
+        const int ge = lo + e;                              /* local incidence */
+        double *p = Tp(e), *tg = Ttg(e), *qd = Tqd(e);
+        for (int k = 0; k < n; ++k) {
+            tg[k] = is_src ? TW(k, ge) : TW(n + k, ge);     /* target of [O]_1 */
+            tg[n + k] = is_src ? TW(n + k, ge) : 0.0;       /* target of [O]_2 (outgoing only) */
+            qd[k] = rho; qd[n + k] = is_src ? rho : 0.0;
+            p[k] = cen[k] / L; p[n + k] = cen[k] / L;
+        }
+        tg[2 * n] = TW(2 * n, ge); qd[2 * n] = rho; p[2 * n] = 1.0 / L;
+    }
+    double t = 1.0, nu = 0.0, ssoc[MAXN + 1], lsoc[MAXN + 1] = {0}, ksoc[MAXN + 1], dssoc[MAXN + 1], dlsoc[MAXN + 1];
+    const int deg = L * R + 1;
+    int status = -1, it, stalled = 0;
+    for (it = 0; it <= ip->ipm_max_iter; ++it) {
+        int interior = 1;
+        double gap = 0;
+        for (int k = 1; k < q; ++k) ssoc[k] = 0;
+        for (int e = 0; e < L; ++e) {
+            const double *p = Tp(e); double *s = Ts(e), *lam = Tlam(e);
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < m; ++j) {
+                    double a = p[2 * n] * b[j];
+                    for (int k = 0; k < n; ++k) a -= A[j * n + k] * p[i * n + k];
+                    s[i * m + j] = a;
+                    if (!(a > 0)) interior = 0;
+                }
+            for (int k = 0; k < n; ++k) ssoc[1 + k] += p[k] - p[n + k];
+        }
+        ssoc[0] = t;
+        if (!interior || !soc_interior(q, ssoc)) { status = -3; break; }
+        if (it == 0) {
+            for (int e = 0; e < L; ++e) for (int r = 0; r < R; ++r) Tlam(e)[r] = 1.0 / Ts(e)[r];
+            lsoc[0] = 1.0 / t;
+        }
+        for (int e = 0; e < L; ++e) for (int r = 0; r < R; ++r) gap += Ts(e)[r] * Tlam(e)[r];
+        for (int k = 0; k < q; ++k) gap += ssoc[k] * lsoc[k];
+        const double mu = gap / deg;
+        if (mu <= ip->ipm_tol || (stalled && mu <= 1e3 * ip->ipm_tol)) { status = 0; break; }
+        if (it == ip->ipm_max_iter) break;
+        /* scalings */
+        double Wsoc[(MAXN + 1) * (MAXN + 1)], Wsoci[(MAXN + 1) * (MAXN + 1)], W2[(MAXN + 1) * (MAXN + 1)], wb[MAXN + 1], eta, lt[MAXN + 1];
+        if (soc_scaling(q, ssoc, lsoc, Wsoc, Wsoci, wb, &eta)) { status = mu <= 1e3 * ip->ipm_tol ? 0 : -4; break; }
+        for (int i = 0; i < q; ++i)
+            for (int j = 0; j < q; ++j) { double a = 0; for (int k = 0; k < q; ++k) a += Wsoci[i * ldq + k] * Wsoci[k * ldq + j]; W2[i * ldq + j] = a; }
+        for (int i = 0; i < q; ++i) { double a = 0; for (int k = 0; k < q; ++k) a += Wsoc[i * ldq + k] * lsoc[k]; lt[i] = a; }
+        /* W^{-2} = [c0 cv'; cv Mu]; t eliminated in closed form (as in the generic vertex): Su = eta^-2 (I - 2 wb1 wb1' / (2 wb0^2 - 1)) */
+        const double ie2 = 1.0 / (eta * eta), g2 = 2.0 / (2.0 * wb[0] * wb[0] - 1.0), c0 = ie2 * (2.0 * wb[0] * wb[0] - 1.0);
+        double cv[MAXN], Su[MAXN * MAXN];
+        for (int k = 0; k < n; ++k) cv[k] = -ie2 * 2.0 * wb[0] * wb[1 + k];
+        for (int k = 0; k < n; ++k) for (int l = 0; l < n; ++l) Su[k * n + l] = ie2 * ((k == l ? 1.0 : 0.0) - g2 * wb[1 + k] * wb[1 + l]);
+        /* block Hessians, factors, X = H^{-1} F', S = sum F X */
+        double S[(MAXN + 1) * (MAXN + 1)] = {0};
+        for (int e = 0; e < L; ++e) {
+            double *H = TH(e), *X = TX(e); const double *s = Ts(e), *lam = Tlam(e), *qd = Tqd(e);
+            memset(H, 0, sizeof(double) * NW * NW);
+            for (int k = 0; k < NW; ++k) H[k * NW + k] = qd[k] + REG_DELTA;
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < m; ++j) {
+                    const double D = lam[i * m + j] / s[i * m + j];
+                    for (int k = 0; k < n; ++k) {
+                        for (int l = 0; l < n; ++l) H[(i * n + k) * NW + i * n + l] += D * A[j * n + k] * A[j * n + l];
+                        H[(i * n + k) * NW + 2 * n] -= D * A[j * n + k] * b[j];
+                        H[2 * n * NW + i * n + k] -= D * A[j * n + k] * b[j];
+                    }
+                    H[2 * n * NW + 2 * n] += D * b[j] * b[j];
+                }
+            chol(NW, H, NW);
+            for (int c = 0; c < NF; ++c) {
+                double col[MAXNW];
+                for (int k = 0; k < NW; ++k) col[k] = 0;
+                if (c < n) { col[c] = 1.0; col[n + c] = -1.0; } else col[2 * n] = 1.0;
+                chol_solve(NW, H, NW, col);
+                for (int k = 0; k < NW; ++k) X[k * NF + c] = col[k];
+            }
+            for (int a = 0; a < NF; ++a)
+                for (int c = 0; c < NF; ++c)
+                    S[a * NF + c] += a < n ? X[a * NF + c] - X[(n + a) * NF + c] : X[2 * n * NF + c];
+        }
+        /* one Newton solve for the multipliers kap (rows) / ksoc (cone) in place of the duals; leaves dp, dt, dnu, ds, dssoc */
+        double dt = 0, dnu = 0;
+#define TERMINAL_NEWTON()                                                                                                        \
+        do {                                                                                                                     \
+            const double gt = 1.0 - ksoc[0];                                                                                     \
+            double z[MAXN + 1] = {0};                                                                                            \
+            for (int e = 0; e < L; ++e) {                                                                                        \
+                const double *p = Tp(e), *tg = Ttg(e), *qd = Tqd(e), *kap = Tkap(e); double *rhs = Trhs(e), *hr = Thr(e);          \
+                double gy = ip->eps_edge + nu;                                                                                   \
+                for (int k = 0; k < NW; ++k) rhs[k] = -(qd[k] * (p[k] - tg[k]) + REG_DELTA * p[k]);                                \
+                for (int i = 0; i < 2; ++i)                                                                                      \
+                    for (int j = 0; j < m; ++j) {                                                                                \
+                        for (int k = 0; k < n; ++k) rhs[i * n + k] -= A[j * n + k] * kap[i * m + j];                               \
+                        gy -= b[j] * kap[i * m + j];                                                                             \
+                    }                                                                                                            \
+                rhs[2 * n] -= gy;                                                                                                \
+                for (int k = 0; k < n; ++k) { rhs[k] += ksoc[1 + k] + cv[k] * gt / c0; rhs[n + k] -= ksoc[1 + k] + cv[k] * gt / c0; } \
+                for (int k = 0; k < NW; ++k) hr[k] = rhs[k];                                                                     \
+                chol_solve(NW, TH(e), NW, hr);                                                                                   \
+                for (int c = 0; c < NF; ++c) { double a = 0; for (int k = 0; k < NW; ++k) a += TX(e)[k * NF + c] * rhs[k]; z[c] += a; } \
+            }                                                                                                                    \
+            double Ms[(MAXN + 1) * (MAXN + 1)], sol[MAXN + 1];                                                                   \
+            for (int a = 0; a < NF; ++a) {                                                                                       \
+                for (int c = 0; c < n; ++c) { double v = 0; for (int k = 0; k < n; ++k) v += S[a * NF + k] * Su[k * n + c]; Ms[a * NF + c] = v + (a == c ? 1.0 : 0.0); } \
+                Ms[a * NF + n] = S[a * NF + n];                                                                                  \
+                sol[a] = z[a];                                                                                                   \
+            }                                                                                                                    \
+            if (gauss_solve(NF, Ms, NF, sol)) { status = -5; goto terminal_done; }                                               \
+            double su[MAXN + 1];                                                                                                 \
+            for (int k = 0; k < n; ++k) { double v = 0; for (int l = 0; l < n; ++l) v += Su[k * n + l] * sol[l]; su[k] = v; }    \
+            su[n] = sol[n]; dnu = sol[n];                                                                                        \
+            for (int k = 1; k < q; ++k) dssoc[k] = 0;                                                                            \
+            for (int e = 0; e < L; ++e) {                                                                                        \
+                double *dp = Tdp(e), *ds = Tds(e); const double *hr = Thr(e), *X = TX(e);                                        \
+                for (int k = 0; k < NW; ++k) { double a = hr[k]; for (int c = 0; c < NF; ++c) a -= X[k * NF + c] * su[c]; dp[k] = a; } \
+                for (int i = 0; i < 2; ++i)                                                                                      \
+                    for (int j = 0; j < m; ++j) { double a = dp[2 * n] * b[j]; for (int k = 0; k < n; ++k) a -= A[j * n + k] * dp[i * n + k]; ds[i * m + j] = a; } \
+                for (int k = 0; k < n; ++k) dssoc[1 + k] += dp[k] - dp[n + k];                                                   \
+            }                                                                                                                    \
+            { double a = -gt; for (int k = 0; k < n; ++k) a -= cv[k] * dssoc[1 + k]; dt = a / c0; }                              \
+            dssoc[0] = dt;                                                                                                       \
+        } while (0)
+        /* predictor */
+        double amax = 1e300, c1 = 0, c2 = 0;
+        for (int e = 0; e < L; ++e) memset(Tkap(e), 0, sizeof(double) * R);
+        for (int k = 0; k < q; ++k) ksoc[k] = 0;
+        TERMINAL_NEWTON();
+        for (int e = 0; e < L; ++e) {
+            double *s = Ts(e), *lam = Tlam(e), *ds = Tds(e), *dl = Tdl(e), *kap = Tkap(e);
+            for (int r = 0; r < R; ++r) { ROW(s[r], lam[r], ds[r], 0.0, dl[r]); kap[r] = ds[r] * dl[r]; }
+        }
+        for (int i = 0; i < q; ++i) { double a = -lsoc[i]; for (int k = 0; k < q; ++k) a -= W2[i * ldq + k] * dssoc[k]; dlsoc[i] = a; }
+        amax = fmin(amax, fmin(soc_max_step(q, ssoc, dssoc), soc_max_step(q, lsoc, dlsoc)));
+        for (int k = 0; k < q; ++k) { c1 += ssoc[k] * dlsoc[k] + lsoc[k] * dssoc[k]; c2 += dssoc[k] * dlsoc[k]; }
+        const double al_aff = fmin(1.0, amax);
+        double sig = (gap + al_aff * c1 + al_aff * al_aff * c2) / deg / mu;
+        sig = sig < 0 ? 0 : (sig > 1 ? 1 : sig); sig = sig * sig * sig;
+        const double sm = sig * mu;
+        /* corrector multipliers */
+        for (int e = 0; e < L; ++e) { double *kap = Tkap(e); const double *s = Ts(e); for (int r = 0; r < R; ++r) kap[r] = (sm - kap[r]) / s[r]; }
+        {
+            double a1[MAXN + 1], a2[MAXN + 1], pr[MAXN + 1], qv[MAXN + 1];
+            for (int i = 0; i < q; ++i) {
+                double u1 = 0, u2 = 0;
+                for (int k = 0; k < q; ++k) { u1 += Wsoci[i * ldq + k] * dssoc[k]; u2 += Wsoc[i * ldq + k] * dlsoc[k]; }
+                a1[i] = u1; a2[i] = u2;
+            }
+            soc_prod(q, a1, a2, pr);
+            soc_div(q, lt, pr, qv);
+            const double dets = soc_det(q, ssoc);
+            for (int i = 0; i < q; ++i) {
+                double a = 0;
+                for (int k = 0; k < q; ++k) a += Wsoci[i * ldq + k] * qv[k];
+                ksoc[i] = sm * (i == 0 ? ssoc[0] : -ssoc[i]) / dets - a;
+            }
+        }
+        TERMINAL_NEWTON();
+        amax = 1e300; c1 = c2 = 0;
+        for (int e = 0; e < L; ++e) {
+            double *s = Ts(e), *lam = Tlam(e), *ds = Tds(e), *dl = Tdl(e), *kap = Tkap(e);
+            for (int r = 0; r < R; ++r) ROW(s[r], lam[r], ds[r], kap[r], dl[r]);
+        }
+        for (int i = 0; i < q; ++i) { double a = ksoc[i] - lsoc[i]; for (int k = 0; k < q; ++k) a -= W2[i * ldq + k] * dssoc[k]; dlsoc[i] = a; }
+        amax = fmin(amax, fmin(soc_max_step(q, ssoc, dssoc), soc_max_step(q, lsoc, dlsoc)));
+        double al = fmin(1.0, 0.99 * amax);
+        for (int tries = 0; tries < 40; ++tries) {
+            double s2[MAXN + 1] = {0}, l2[MAXN + 1] = {0};
+            for (int k = 0; k < q; ++k) { s2[k] = ssoc[k] + al * dssoc[k]; l2[k] = lsoc[k] + al * dlsoc[k]; }
+            if (soc_interior(q, s2) && soc_interior(q, l2)) break;
+            al *= 0.7;
+        }
+        stalled = al < 1e-3;
+        for (int e = 0; e < L; ++e) {
+            double *p = Tp(e), *lam = Tlam(e); const double *dp = Tdp(e), *dl = Tdl(e);
+            for (int k = 0; k < NW; ++k) p[k] += al * dp[k];
+            for (int r = 0; r < R; ++r) lam[r] += al * dl[r];
+        }
+        t += al * dt; nu += al * dnu;
+        for (int k = 0; k < q; ++k) lsoc[k] += al * dlsoc[k];
+    }
+terminal_done:
+    if (status != 0) return status < -1 ? status : -1;
+    for (int k = 0; k < 2 * n; ++k) xv[k] = 0;
+    for (int e = 0; e < d; ++e) {
+        const int live = e >= lo && e < hi, outgoing = e >= d_in;
+        const double *p = live ? Tp(e - lo) : NULL;
+        for (int k = 0; k < n; ++k) {
+            CW(k, e) = outgoing ? (live ? p[k] : 0.0) : TW(k, e);
+            CW(n + k, e) = live ? (outgoing ? p[n + k] : p[k]) : 0.0;
+        }
+        CW(2 * n, e) = live ? p[2 * n] : 0.0;
+        if (live) for (int k = 0; k < 2 * n; ++k) xv[k] += p[k];
+    }
+    for (int k = 0; k < 2 * n; ++k) zv[k] = xv[k];
+    *yv = 1.0;
+    return it;
+}
+
 int oracle_solve_vertex(int n, int m, const double *A, const double *b_raw, const double *cen,
                         int d, int d_in, int is_src, int is_dst, const double *T, double rho,
                         const oracle_inner_params *ip, double *copy, double *xv, double *zv, double *yv, double *warm)
 {
     const int NW = 2 * n + 1, NX = 2 * n, NB = 4 * n + 2, q = n + 1, c = 2 * n + 1;
     const int d_out = d - d_in;
-#define TW(k, e) T[(k) * d + (e)]
-#define CW(k, e) copy[(k) * d + (e)]
+    if ((is_src || is_dst) && terminal_extent(n, m, A, b_raw, cen) > 1e-5)
+        return solve_terminal_region(n, m, A, b_raw, cen, d, d_in, is_src, T, rho, ip, copy, xv, zv, yv);
     if (is_src || is_dst) {
         /* point vertex (box of half-width 1e-6 around cen): O_{e,i} = y_e * pt on the live side,
          * sum y_e = 1 -> separable quadratic over the simplex; the other side is dead (y = 0). */
@@ -888,11 +1156,6 @@ restart:
         lagr_grad(&P, gb);
         newton_solve(&P, &F, gb, rp, db, dnu);
         slack_dir(&P, db, ds1, ds2, dsyv, dssoc, -1, NULL, NULL, NULL, NULL);
-#define ROW(sv, lv, dsv, kv, dlout)                                                          \
-    do { double D_ = (lv) / (sv); double dl_ = (kv) - (lv) - D_ * (dsv); (dlout) = dl_;        \
-         if ((dsv) < 0) { amax = fmin(amax, -(sv) / (dsv)); }                                \
-         if (dl_ < 0) { amax = fmin(amax, -(lv) / dl_); }                                    \
-         c1 += (sv) * dl_ + (lv) * (dsv); c2 += (dsv) * dl_; } while (0)
         for (int r = 0; r < R; ++r) { ROW(P.s1[r], P.l1[r], ds1[r], 0.0, dl1[r]); ROW(P.s2[r], P.l2[r], ds2[r], 0.0, dl2[r]); }
         ROW(P.syv[0], P.lyv[0], dsyv[0], 0.0, dlyv[0]); ROW(P.syv[1], P.lyv[1], dsyv[1], 0.0, dlyv[1]);
         for (int i = 0; i < q; ++i) {
