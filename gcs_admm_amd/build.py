@@ -13,17 +13,19 @@ MAIN = os.path.join(CSRC, "gcsadmm.hip")
 WG = os.path.join(CSRC, "vertex_wg.hip")        # workgroup-cooperative vertex program (n = 2, 3, 6; own object)
 WGD = os.path.join(CSRC, "vertex_wg_dims.hip")  # the same program for n = 1, 4, 5 (own object: the builds run in parallel)
 LP = os.path.join(CSRC, "polytope_lp.hip")      # batched tiny LPs for graph construction (own object, own dependencies)
+TERM = os.path.join(CSRC, "terminal_region.hip")  # x-update of terminals that are regions (own object)
 # (source, object name, extra flags)
 # vertex_wg.hip is built twice: 256 threads per workgroup, and 512 for launches of at most one workgroup per CU (own namespace and entry points)
 T512 = ["-DGCS_WG_THREADS=512", "-Dgcs_wg=gcs_wg_t512", "-DGCS_WG_SYM(name)=name##_t512"]
 UNITS = [(MAIN, "gcsadmm.o", []), (WG, "vertex_wg.o", []), (WG, "vertex_wg_t512.o", T512), (WGD, "vertex_wg_dims.o", []), (WGD, "vertex_wg_dims_t512.o", T512),
-         (LP, "polytope_lp.o", [])]
+         (LP, "polytope_lp.o", []), (TERM, "terminal_region.o", [])]
 HDR = os.path.join(ROOT, "include", "gcsadmm.h")
 _c = lambda *names: [os.path.join(CSRC, f) for f in names]
-DEPS = [MAIN, HDR] + _c("vertex_program.h", "vertex_program.inc", "vertex_kernel.h", "special_vertex.h", "vertex_wg_launch.h", "canonical_box.h", "warm_start.h")
+DEPS = [MAIN, HDR] + _c("vertex_program.h", "vertex_program.inc", "vertex_kernel.h", "special_vertex.h", "vertex_wg_launch.h", "canonical_box.h", "warm_start.h", "terminal_launch.h")
 UNIT_DEPS = {LP: [LP, HDR] + _c("polytope_lp_core.h"),
              WG: [WG, HDR] + _c("vertex_wg.h", "vertex_wg_kernel.h", "vertex_wg_launch.h", "special_vertex.h", "gcs_math.h", "warm_start.h")}
 UNIT_DEPS[WGD] = [WGD] + UNIT_DEPS[WG][1:]
+UNIT_DEPS[TERM] = [TERM, HDR] + _c("terminal_region.h", "terminal_launch.h", "gcs_math.h")
 OUT = os.path.join(HERE, "libgcsadmm.so")
 
 
@@ -36,7 +38,7 @@ def hipcc() -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """The objects are compiled concurrently, then linked."""
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + UNIT_DEPS[LP] + UNIT_DEPS[WG] + UNIT_DEPS[WGD]):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS + UNIT_DEPS[LP] + UNIT_DEPS[WG] + UNIT_DEPS[WGD] + UNIT_DEPS[TERM]):
         return OUT
     # the compiler's per-kernel resource remarks (registers, scratch, LDS) are kept next to each object: kernel_resources()
     flags = ["-Rpass-analysis=kernel-resource-usage", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -93,7 +95,7 @@ def build_timing() -> str:
     build()
     obj = os.path.join(HERE, "vertex_wg_t512_timing.o")
     subprocess.check_call([hipcc()] + flags + T512 + ["-DGCS_WG_TIMING", "-c", WG, "-o", obj])
-    objs = [os.path.join(HERE, n) for n in ("gcsadmm.o", "polytope_lp.o", "vertex_wg.o", "vertex_wg_dims.o", "vertex_wg_dims_t512.o")] + [obj]
+    objs = [os.path.join(HERE, n) for n in ("gcsadmm.o", "polytope_lp.o", "terminal_region.o", "vertex_wg.o", "vertex_wg_dims.o", "vertex_wg_dims_t512.o")] + [obj]
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
     return out
 

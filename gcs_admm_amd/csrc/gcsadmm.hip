@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "gcsadmm.h"
+#include "terminal_launch.h"
 #ifdef GCS_PHASE_TIMING
 // diagnostic build: sub-phase stamps inside the border factorisation (lane 0 of each wavefront)
 __device__ unsigned long long g_sub_cycles[16];
@@ -392,6 +393,12 @@ struct gcsadmm_handle_s {
     int *d_split_ids = nullptr, *d_split_order = nullptr;    // [n_waves] static ids / launch order: boundary wavefronts first, then interior
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
+    // terminals that are regions (terminal_region.h): at most two, one workgroup each, on an auxiliary stream beside the vertex-step launch
+    int n_term = 0, term_vtx[2] = {-1, -1}, term_is_src[2] = {0, 0};
+    long long term_ws_off[2] = {0, 0};
+    double *d_term_ws = nullptr;
+    hipStream_t term_stream = nullptr;
+    hipEvent_t ev_term_fork = nullptr, ev_term_join = nullptr;
 };
 
 // ---- RCCL, bound at run time ----
@@ -516,8 +523,36 @@ static WgLaunchDesc make_wg_desc(gcsadmm_handle h, const gcsadmm_state *st, bool
 
 // part: -1 the whole vertex step; 0 / 1 the boundary / interior wavefronts of the overlapped partitioned loop (handles whose generic
 // vertices are all on the wavefront program; the closed-form vertices ride with the boundary part)
+static gcsadmm_k::TermLaunchDesc make_term_desc(gcsadmm_handle h, const gcsadmm_state *st)
+{
+    gcsadmm_k::TermLaunchDesc d;
+    d.n = h->n; d.dtype = h->dtype; d.count = h->n_term;
+    for (int i = 0; i < 2; ++i) { d.vtx[i] = h->term_vtx[i]; d.is_src[i] = h->term_is_src[i]; d.ws_off[i] = h->term_ws_off[i]; }
+    d.ws = h->d_term_ws;
+    d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
+    d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
+    d.E = h->E; d.NI = h->NI; d.edge_major = h->edge_major;
+    d.zedge = st->zedge; d.mu = st->mu; d.copy = st->copy; d.xv = st->xv; d.zv = st->zv; d.yv = st->yv;
+    d.counters = h->d_counters; d.cb = h->d_cb;
+    d.eps_edge = h->params.eps_edge; d.ipm_tol = h->params.ipm_tol; d.ipm_max_iter = h->params.ipm_max_iter;
+    return d;
+}
+
 template <class T> static gcsadmm_status launch_vertex(gcsadmm_handle h, const gcsadmm_state *st, hipStream_t s, int part = -1, bool reorder = false)
 {
+    // terminals that are regions: their kernel runs on the auxiliary stream beside the launches below (it is a latency-bound solve in
+    // one or two workgroups; the vertex launches do not wait for it, the caller's stream does at the end)
+    const bool with_term = h->n_term > 0 && part <= 0;
+    if (with_term) {
+        HIPCHK(h, hipEventRecord(h->ev_term_fork, s));
+        HIPCHK(h, hipStreamWaitEvent(h->term_stream, h->ev_term_fork, 0));
+        gcsadmm_terminal_launch(make_term_desc(h, st), h->term_stream);
+        HIPCHK(h, hipEventRecord(h->ev_term_join, h->term_stream));
+    }
+    struct Join {       // (every return path below joins)
+        gcsadmm_handle h; hipStream_t s; bool on;
+        ~Join() { if (on) (void)hipStreamWaitEvent(s, h->ev_term_join, 0); }
+    } join_{h, s, with_term};
     if (part >= 0) {
         VertexLaunchDesc d = make_launch_desc(h, st);
         const int off = part ? h->n_wave_b : 0, cnt = part ? h->n_waves - h->n_wave_b : h->n_wave_b;
@@ -761,6 +796,10 @@ void gcsadmm_destroy(gcsadmm_handle h)
         if (p) (void)hipFree(p);
     halo_free(h);
     overlap_free(h);
+    if (h->d_term_ws) (void)hipFree(h->d_term_ws);
+    if (h->ev_term_fork) (void)hipEventDestroy(h->ev_term_fork);
+    if (h->ev_term_join) (void)hipEventDestroy(h->ev_term_join);
+    if (h->term_stream) (void)hipStreamDestroy(h->term_stream);
     if (h->comm && rccl().ok()) (void)rccl().CommDestroy((ncclComm_t)h->comm);
     for (auto ev : h->events) (void)hipEventDestroy(ev);
     delete h;
@@ -827,28 +866,34 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     // closed form: s, t (points) and vertices no flow can cross; generic: an interior-point solve each.  A generic vertex
     // goes to the WORKGROUP program (vertex_wg.hip) when the wavefront program cannot take it (n != 2, more than 63
     // incident edges) or when the graph is small enough that latency, not throughput, decides (or on request).
-    auto is_special = [&](int v) {
-        const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
-        return v == g->src || v == g->dst || din == 0 || d - din == 0;
-    };
-    // s / t are treated as points (utils.py:12-28 turns them into boxes of half-width 1e-6): a terminal whose polytope has
-    // any extent would silently be replaced by its centre -- refuse it instead.
+    // s / t: the reference builds them as points (utils.py:12-28, boxes of half-width 1e-6) -> closed form (special_vertex.h).  A terminal
+    // whose polytope has an extent is a REGION: its sub-problem is the reference's with delta_sv / delta_tv (admm_solver_v3.py:450-464),
+    // solved by terminal_region.h.  Extent = the widest distance from `center` to a facet; the rule the oracle uses (terminal_extent).
+    int term_vtx[2] = {-1, -1}, term_is_src[2] = {0, 0}, n_term = 0;
     for (int term : {g->src, g->dst}) {
         if (term < 0 || term >= V) continue;
-        // widest slack of a facet pair along any facet normal bounds the extent: b_j - a_j c over all facets is the distance
-        // (times |a_j|) from the centre to facet j; a point-like box has all of them <= ~1e-5
         double ext = 0;
         for (int j = g->poly_ptr[term]; j < g->poly_ptr[term + 1]; ++j) {
             double nrm = 0;
             for (int k = 0; k < n; ++k) nrm += g->poly_A[(size_t)j * n + k] * g->poly_A[(size_t)j * n + k];
             ext = std::max(ext, std::fabs(bc[j]) / std::sqrt(nrm > 0 ? nrm : 1.0));
         }
-        if (ext > 1e-5)
-            return fail(GCSADMM_ERR_UNSUPPORTED, "the source / target set must be a point (a box of half-width <= 1e-5 about `center`): "
-                                                 "its polytope is not used by the closed-form terminal update");
+        if (ext > 1e-5) {
+            const int d = g->inc_ptr[term + 1] - g->inc_ptr[term], din = deg_in[term];
+            if (g->src == g->dst) return fail(GCSADMM_ERR_UNSUPPORTED, "source and target are the same region");
+            if ((term == g->src ? d - din : din) < 1)
+                return fail(GCSADMM_ERR_UNSUPPORTED, "a terminal that is a region needs an edge on its live side (outgoing for the source, incoming for the target)");
+            term_vtx[n_term] = term; term_is_src[n_term] = term == g->src; ++n_term;
+        }
     }
+    auto is_region_terminal = [&](int v) { return (n_term > 0 && v == term_vtx[0]) || (n_term > 1 && v == term_vtx[1]); };
+    auto is_special = [&](int v) {
+        if (is_region_terminal(v)) return false;
+        const int d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
+        return v == g->src || v == g->dst || din == 0 || d - din == 0;
+    };
     int n_generic = 0;
-    for (int v = 0; v < V; ++v) n_generic += !is_special(v);
+    for (int v = 0; v < V; ++v) n_generic += !is_special(v) && !is_region_terminal(v);
     // Crossover of the two programs on n = 2 (measured on box lattices, profiles/r02/README.md: 1 024 vertices 3 570 vs 3 030 it/s,
     // 1 444 vertices 2 410 vs 3 060): the workgroup program holds 4 workgroups per CU (102 registers), i.e. 1 024 vertices in one
     // round of ~0.28 ms; the wavefront program packs up to 7 vertices per wavefront and serves up to ~7 000 in one round of 0.33 ms.
@@ -864,6 +909,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     for (int v = 0; v < V; ++v) {
         const int d = g->inc_ptr[v + 1] - g->inc_ptr[v];
         const int m = g->poly_ptr[v + 1] - g->poly_ptr[v];
+        if (is_region_terminal(v)) continue;      // its own kernel
         if (is_special(v)) {
             if (d > MAX_SPECIAL_DEG) return fail(GCSADMM_ERR_UNSUPPORTED, "terminal vertex degree above 256");
             special_vtx.push_back(v);
@@ -1014,10 +1060,23 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_partials, (const double *)nullptr, (size_t)h->edge_blocks * 5);
     UP(d_sums, (const double *)nullptr, 5);
     UP(d_ticket, (const unsigned *)nullptr, 1);
+    if (n_term > 0) {       // region terminals: workspace, an auxiliary stream and the fork / join events
+        long long off = 0;
+        for (int i = 0; i < n_term; ++i) {
+            const int v = term_vtx[i], d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
+            h->term_vtx[i] = v; h->term_is_src[i] = term_is_src[i]; h->term_ws_off[i] = off;
+            off += gcsadmm_terminal_ws_doubles(n, g->poly_ptr[v + 1] - g->poly_ptr[v], term_is_src[i] ? d - din : din);
+        }
+        h->n_term = n_term;
+        UP(d_term_ws, (const double *)nullptr, (size_t)off);
+        if ((e = hipStreamCreateWithFlags(&h->term_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+        if ((e = hipEventCreateWithFlags(&h->ev_term_fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&h->ev_term_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
     {   // warm-start workspace: one record per generic vertex (either program), none for the closed-form ones; zero = no record
         std::vector<long long> wp(V + 1, 0);
         for (int v = 0; v < V; ++v)
-            wp[v + 1] = wp[v] + (is_special(v) ? 0 : gcs_ws::warm_record_doubles(n, g->poly_ptr[v + 1] - g->poly_ptr[v], g->inc_ptr[v + 1] - g->inc_ptr[v]));
+            wp[v + 1] = wp[v] + ((is_special(v) || is_region_terminal(v)) ? 0 : gcs_ws::warm_record_doubles(n, g->poly_ptr[v + 1] - g->poly_ptr[v], g->inc_ptr[v + 1] - g->inc_ptr[v]));
         h->warm_doubles = (size_t)wp[V];
         UP(d_warm_ptr, wp.data(), V + 1);
         UP(d_warm, (const double *)nullptr, h->warm_doubles);
@@ -1339,6 +1398,7 @@ gcsadmm_status gcsadmm_vertex_prox(gcsadmm_handle h, const double *q_dev, const 
 {
     if (!h || !q_dev || !c_dev || !xv_dev || !zv_dev || !yv_dev || !(ipm_tol > 0) || ipm_max_iter < 1) { if (h) h->err = "bad prox argument"; return GCSADMM_ERR_BAD_ARG; }
     if (h->prox_lds_bytes > 160 * 1024) { h->err = "facet count too large for LDS"; return GCSADMM_ERR_UNSUPPORTED; }
+    if (h->n_term > 0) { h->err = "the prox kernel (v1 x-update) takes its terminals as points; this graph has a terminal that is a region"; return GCSADMM_ERR_UNSUPPORTED; }
     USE_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(h, hipMemsetAsync(h->d_prox_counters, 0, 2 * sizeof(int), s));

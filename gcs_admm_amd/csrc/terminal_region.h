@@ -44,6 +44,7 @@ template <int N> struct TermShared {
     double ssoc[Q], lsoc[Q], ksoc[Q], dssoc[Q], dlsoc[Q], lt[Q];
     double Wsoc[Q * Q], Wsoci[Q * Q], W2[Q * Q], Su[N * N], cv[N];
     double S[NF * NF], z[NF], su[NF];
+    double M[NF * NF], x[NF];         // the small system of a Newton solve (thread 0; dynamic row swaps: kept out of registers)
     double c0, t, nu, dt, dnu, mu, gap, sm, al;
     int status, stalled, stop;
 };
@@ -127,7 +128,7 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
     auto newton = [&]() {
         const double gt = 1.0 - sh.ksoc[0], ct = gt / sh.c0;
         for (int e = tid; e < L; e += nt) {
-            double r[NW];
+            double *r = rhs + e * NW, *h = hr + e * NW;
             const double *pe = pp + e * NW, *te = tg + e * NW, *qe = qd + e * NW, *ke = kap + e * R;
             for (int k = 0; k < NW; ++k) r[k] = -(qe[k] * (pe[k] - te[k]) + TERM_REG * pe[k]);
             double gy = P.eps_edge + sh.nu;
@@ -141,16 +142,14 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
             for (int k = 0; k < N; ++k) { const double c = sh.ksoc[1 + k] + sh.cv[k] * ct; r[k] += c; r[N + k] -= c; }
             const double *Le = H + (size_t)e * NW * NW, *Xe = X + (size_t)e * NW * NF;
             for (int c = 0; c < NF; ++c) { double a = 0; for (int k = 0; k < NW; ++k) a += Xe[k * NF + c] * r[k]; zc[e * NF + c] = a; }
-            for (int k = 0; k < NW; ++k) rhs[e * NW + k] = r[k];
-            for (int i = 0; i < NW; ++i) { double a = r[i]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * r[k]; r[i] = a / Le[i * NW + i]; }
-            for (int i = NW - 1; i >= 0; --i) { double a = r[i]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * r[k]; r[i] = a / Le[i * NW + i]; }
-            for (int k = 0; k < NW; ++k) hr[e * NW + k] = r[k];
+            for (int i = 0; i < NW; ++i) { double a = r[i]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * h[k]; h[i] = a / Le[i * NW + i]; }
+            for (int i = NW - 1; i >= 0; --i) { double a = h[i]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * h[k]; h[i] = a / Le[i * NW + i]; }
         }
         ex.sync();
         for (int c = tid; c < NF; c += nt) { double a = 0; for (int e = 0; e < L; ++e) a += zc[e * NF + c]; sh.z[c] = a; }
         ex.sync();
         if (tid == 0) {       // (I + S_uu Su) du + S_uy dnu = z_u ;  S_yu Su du + S_yy dnu = z_y : Gaussian elimination, partial pivoting
-            double M[NF * NF], x[NF];
+            double *M = sh.M, *x = sh.x;
             for (int a = 0; a < NF; ++a) {
                 for (int c = 0; c < N; ++c) { double v = 0; for (int k = 0; k < N; ++k) v += sh.S[a * NF + k] * sh.Su[k * N + c]; M[a * NF + c] = v + (a == c ? 1.0 : 0.0); }
                 M[a * NF + N] = sh.S[a * NF + N];
@@ -293,27 +292,24 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         // ---- per block: Cholesky in place (clamped pivots), X = H^{-1} F'
         for (int e = tid; e < L; e += nt) {
             double *Le = H + (size_t)e * NW * NW, *Xe = X + (size_t)e * NW * NF;
-            double diag[NW];
-            for (int j = 0; j < NW; ++j) diag[j] = Le[j * NW + j];
             for (int j = 0; j < NW; ++j) {
-                double dj = Le[j * NW + j];
+                const double d0 = Le[j * NW + j];       // (column j is untouched until now: the entry of H itself)
+                double dj = d0;
                 for (int k = 0; k < j; ++k) dj -= Le[j * NW + k] * Le[j * NW + k];
-                if (!(dj > TERM_CHOL_SKIP * diag[j])) dj = diag[j] > 0 ? TERM_CHOL_SKIP * diag[j] : 1.0;
+                if (!(dj > TERM_CHOL_SKIP * d0)) dj = d0 > 0 ? TERM_CHOL_SKIP * d0 : 1.0;
                 dj = sqrt(dj);
                 Le[j * NW + j] = dj;
                 for (int i = j + 1; i < NW; ++i) {
-                    double s = Le[i * NW + j];
-                    for (int k = 0; k < j; ++k) s -= Le[i * NW + k] * Le[j * NW + k];
-                    Le[i * NW + j] = s / dj;
+                    double sv = Le[i * NW + j];
+                    for (int k = 0; k < j; ++k) sv -= Le[i * NW + k] * Le[j * NW + k];
+                    Le[i * NW + j] = sv / dj;
                 }
             }
-            for (int c = 0; c < NF; ++c) {
-                double col[NW];
-                for (int k = 0; k < NW; ++k) col[k] = 0.0;
-                if (c < N) { col[c] = 1.0; col[N + c] = -1.0; } else col[2 * N] = 1.0;
-                for (int i = 0; i < NW; ++i) { double a = col[i]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * col[k]; col[i] = a / Le[i * NW + i]; }
-                for (int i = NW - 1; i >= 0; --i) { double a = col[i]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * col[k]; col[i] = a / Le[i * NW + i]; }
-                for (int k = 0; k < NW; ++k) Xe[k * NF + c] = col[k];
+            for (int c = 0; c < NF; ++c) {      // column c of X = H^{-1} F', solved in place
+                for (int k = 0; k < NW; ++k) Xe[k * NF + c] = 0.0;
+                if (c < N) { Xe[c * NF + c] = 1.0; Xe[(N + c) * NF + c] = -1.0; } else Xe[2 * N * NF + c] = 1.0;
+                for (int i = 0; i < NW; ++i) { double a = Xe[i * NF + c]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * Xe[k * NF + c]; Xe[i * NF + c] = a / Le[i * NW + i]; }
+                for (int i = NW - 1; i >= 0; --i) { double a = Xe[i * NF + c]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * Xe[k * NF + c]; Xe[i * NF + c] = a / Le[i * NW + i]; }
             }
         }
         ex.sync();

@@ -220,18 +220,99 @@ def test_inner_failure_keeps_previous_copy(torch_gpu):
         assert len(kept) >= cb.inner_failures - 0 and len(kept) >= len(generic) - 4, (len(kept), len(generic), cb.inner_failures)
 
 
-def test_terminal_with_extent_is_refused(torch_gpu):
-    """'s' / 't' are treated as points (utils.py:12-28 makes them boxes of half-width 1e-6): a terminal that is a real region
-    is refused with GCSADMM_ERR_UNSUPPORTED instead of being silently replaced by its centre"""
+def _region_row():
+    """three boxes in a row, the outer two are the terminals: s = [0,1] x [0,1], t = [2,3] x [0,1], between them [0.8,2.2] x [0,1].
+    Shortest path: leave s and enter t at the faces x = 1 and x = 2 -> length 1 (with point terminals at the box centres: 2)"""
+    from gcs_admm_amd.graph import graph_from_sets
+    A = np.vstack([np.eye(2), -np.eye(2)])
+    box = lambda x0, x1, y0, y1: (A, np.array([x1, y1, -x0, -y0], float))
+    As, bs = {}, {}
+    As['s'], bs['s'] = box(0, 1, 0, 1); As['t'], bs['t'] = box(2, 3, 0, 1); As[0], bs[0] = box(0.8, 2.2, 0, 1)
+    return graph_from_sets(As, bs, 2)
+
+
+def _region_scene(seed, half=0.35):
+    """a 4 x 4 polygon scene (tools/scale_demo.py) whose terminals are boxes of half-width `half` about the points they were"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from scale_demo import polygon_scene
+    from gcs_admm_amd.graph import graph_from_sets
+    As, bs = polygon_scene(4, seed=seed, m=3 + seed % 4)
+    A = np.vstack([np.eye(2), -np.eye(2)])
+    for key in ('s', 't'):
+        pt = 0.5 * (bs[key][:2] - bs[key][2:])
+        As[key], bs[key] = A, np.hstack([pt + half, -pt + half])
+    return graph_from_sets(As, bs, 2)
+
+
+@pytest.mark.parametrize("program,columns,dtype", [("workgroup", "incidence", "f64"), ("wavefront", "edge", "f64"), ("workgroup", "edge", "f32")])
+def test_region_terminals_vertex_step_against_oracle(torch_gpu, oracle_lib, program, columns, dtype):
+    """'s' / 't' that are regions (admm_solver_v3.py:415-464 with delta_sv / delta_tv; the reference's own cases make them points,
+    utils.py:12-28): the terminal kernel (csrc/terminal_region.h) against the oracle's solve_terminal_region, vertex step by vertex step
+    along an oracle run and from perturbed states, on the terminals' own columns to 1e-5 (f32 state: 2e-4) and everywhere to the fixture bound"""
+    from oracle.oracle import Oracle
+    torch = torch_gpu
+    rng = np.random.default_rng(3)
+    for g in (_region_row(), _region_scene(1), _region_scene(2, half=0.2)):
+        o = Oracle(g, ipm_tol=IPM_TOL)
+        d = _solver(g, dtype, program=program, columns=columns)
+        d.reset()
+        tcols = np.concatenate([np.arange(g.inc_ptr[v], g.inc_ptr[v + 1]) for v in (g.src, g.dst)])
+        for it in range(10):
+            if it >= 6:
+                o.zedge += 0.03 * rng.normal(size=o.zedge.shape); o.mu += 0.02 * rng.normal(size=o.mu.shape)
+            perm = torch.from_numpy(d.col_of).cuda()      # incidence column -> state column (edge-major handles)
+            d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu[:, perm] = torch.from_numpy(o.mu).to(d.mu.dtype).cuda()
+            d.vertex_step()
+            assert o.vertex_step(1.0, 1.0) == 0
+            got = d.copy[:, perm].double().cpu().numpy()
+            assert np.abs(got[:, tcols] - o.copy[:, tcols]).max() < (1e-5 if dtype == "f64" else 2e-4), (it, np.abs(got[:, tcols] - o.copy[:, tcols]).max())
+            assert np.abs(got - o.copy).max() < 2e-3
+            xv = d.xv.cpu().numpy(); zv = d.zv.cpu().numpy()
+            for v in (g.src, g.dst):
+                assert np.abs(xv[v] - o.xv[v]).max() < (1e-5 if dtype == "f64" else 2e-4) and np.array_equal(xv[v], zv[v]) and d.yv[v].item() == 1.0
+            assert d.read_control().inner_failures == 0
+            o.edge_step(1.0)
+        d.close()
+
+
+def test_region_terminals_whole_run(torch_gpu, oracle_lib):
+    """the loop with region terminals to the reference's stop rule: same stop iteration and residual trace as the oracle; on the row of
+    three boxes the cost is the known answer (length 1 between the faces x = 1 and x = 2, + 2 edges x 1e-4), where point terminals at
+    the box centres give 2"""
+    from oracle.oracle import Oracle
+    g = _region_row()
+    o = Oracle(g, ipm_tol=IPM_TOL)
+    ro = o.run(max_it=1000)
+    d = _solver(g)
+    res = d.solve()
+    assert res["status"] == "converged" and res["iterations"] == ro["iterations"]
+    assert abs(res["cost"] - 1.0002) < 1e-2 and abs(res["cost"] - ro["cost"]) < 1e-6
+    for key in ("pri_res_seq", "dual_res_seq"):
+        a, b = np.asarray(res[key]), np.asarray(ro[key])
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+    g2 = _region_scene(1)
+    o2 = Oracle(g2, ipm_tol=IPM_TOL)
+    r2 = o2.run(max_it=1000)
+    for program in ("workgroup", "wavefront"):
+        d2 = _solver(g2, program=program)
+        res2 = d2.solve()
+        assert res2["iterations"] == r2["iterations"] and abs(res2["cost"] - r2["cost"]) < 1e-5 * max(1.0, abs(r2["cost"])), (program, res2["iterations"], r2["iterations"])
+        d2.close()
+
+
+def test_region_terminal_refusals(torch_gpu):
+    """a region terminal with no edge on its live side cannot carry the unit of flow (the reference's program is infeasible there):
+    refused at create; the prox kernel (v1 x-update) keeps point terminals"""
     from gcs_admm_amd import solver
     from gcs_admm_amd.graph import convert_pt_to_polytope, graph_from_sets
     A = np.vstack([np.eye(2), -np.eye(2)])
     As, bs = {}, {}
-    As['s'], bs['s'] = A, np.array([0.5, 0.5, 0.5, 0.5])                  # a box of half-width 0.5, not a point
+    As['s'], bs['s'] = A, np.array([0.5, 0.5, 0.5, 0.5])
     As['t'], bs['t'] = convert_pt_to_polytope(np.array([3.0, 0.0]))
     As[0], bs[0] = A, np.array([4.0, 1.0, 1.0, 1.0])
-    g = graph_from_sets(As, bs, 2)
-    with pytest.raises(solver.GcsAdmmError, match="point"):
+    g = graph_from_sets(As, bs, 2, edges=[(0, 's'), (0, 't')])            # nothing leaves s
+    with pytest.raises(solver.GcsAdmmError, match="live side"):
         _solver(g)
 
 
