@@ -95,7 +95,9 @@ def build_timing() -> str:
     build()
     obj = os.path.join(HERE, "vertex_wg_t512_timing.o")
     subprocess.check_call([hipcc()] + flags + T512 + ["-DGCS_WG_TIMING", "-c", WG, "-o", obj])
-    objs = [os.path.join(HERE, n) for n in ("gcsadmm.o", "polytope_lp.o", "terminal_region.o", "vertex_wg.o", "vertex_wg_dims.o", "vertex_wg_dims_t512.o")] + [obj]
+    tobj = os.path.join(HERE, "terminal_region_timing.o")       # the region-terminal solve with its phase stamps (tools/term_phase_timing.py)
+    subprocess.check_call([hipcc()] + flags + ["-DGCS_TERM_TIMING", "-c", TERM, "-o", tobj])
+    objs = [os.path.join(HERE, n) for n in ("gcsadmm.o", "polytope_lp.o", "vertex_wg.o", "vertex_wg_dims.o", "vertex_wg_dims_t512.o")] + [obj, tobj]
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
     return out
 

@@ -397,6 +397,7 @@ struct gcsadmm_handle_s {
     int n_term = 0, term_vtx[2] = {-1, -1}, term_is_src[2] = {0, 0};
     long long term_ws_off[2] = {0, 0};
     double *d_term_ws = nullptr;
+    int term_threads = 256, term_lds_doubles = 0;     // launch shape: one wavefront and LDS work arrays for small terminals
     hipStream_t term_stream = nullptr;
     hipEvent_t ev_term_fork = nullptr, ev_term_join = nullptr;
 };
@@ -528,7 +529,7 @@ static gcsadmm_k::TermLaunchDesc make_term_desc(gcsadmm_handle h, const gcsadmm_
     gcsadmm_k::TermLaunchDesc d;
     d.n = h->n; d.dtype = h->dtype; d.count = h->n_term;
     for (int i = 0; i < 2; ++i) { d.vtx[i] = h->term_vtx[i]; d.is_src[i] = h->term_is_src[i]; d.ws_off[i] = h->term_ws_off[i]; }
-    d.ws = h->d_term_ws;
+    d.ws = h->d_term_ws; d.threads = h->term_threads; d.lds_doubles = h->term_lds_doubles;
     d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
     d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
     d.E = h->E; d.NI = h->NI; d.edge_major = h->edge_major;
@@ -1061,13 +1062,20 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_sums, (const double *)nullptr, 5);
     UP(d_ticket, (const unsigned *)nullptr, 1);
     if (n_term > 0) {       // region terminals: workspace, an auxiliary stream and the fork / join events
-        long long off = 0;
+        long long off = 0, largest = 0;
+        int rows = 0;
         for (int i = 0; i < n_term; ++i) {
-            const int v = term_vtx[i], d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v];
+            const int v = term_vtx[i], d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], live = term_is_src[i] ? d - din : din;
+            const long long need = gcsadmm_terminal_ws_doubles(n, g->poly_ptr[v + 1] - g->poly_ptr[v], live);
             h->term_vtx[i] = v; h->term_is_src[i] = term_is_src[i]; h->term_ws_off[i] = off;
-            off += gcsadmm_terminal_ws_doubles(n, g->poly_ptr[v + 1] - g->poly_ptr[v], term_is_src[i] ? d - din : din);
+            off += need; largest = std::max(largest, need);
+            rows = std::max(rows, live * 2 * (g->poly_ptr[v + 1] - g->poly_ptr[v]));
         }
         h->n_term = n_term;
+        // the solve is latency-bound: work arrays in LDS while they fit 48 KB, one wavefront (barriers and reductions stay inside it)
+        // while no phase has more than four passes over its rows
+        h->term_lds_doubles = largest * 8 <= 48 * 1024 ? (int)largest : 0;
+        h->term_threads = rows <= 256 ? 64 : 256;
         UP(d_term_ws, (const double *)nullptr, (size_t)off);
         if ((e = hipStreamCreateWithFlags(&h->term_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
         if ((e = hipEventCreateWithFlags(&h->ev_term_fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");

@@ -12,6 +12,8 @@ struct TermLaunchDesc {
     int vtx[2], is_src[2];
     long long ws_off[2];            // workspace of each terminal, ws + ws_off[i], gcsadmm_terminal_ws_doubles(n, facets, live edges) doubles
     double *ws;
+    int threads;                    // 64 (one wavefront: small terminals) or 256
+    int lds_doubles;                // > 0: the work arrays of every terminal fit this much dynamic LDS and live there; 0: in ws
     const int *inc_ptr, *deg_in, *inc_edge, *poly_ptr;
     const double *poly_A, *poly_bc, *center;
     int E, NI, edge_major;

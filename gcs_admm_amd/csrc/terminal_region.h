@@ -16,10 +16,11 @@
 // onto (du, dnu), n + 1 unknowns.  The CPU restatement is oracle/gcs_oracle.c solve_terminal_region (checked there against the
 // sub-problem as written, tests/test_terminal_region.py).
 //
-// Written against an executor EX (tid, nthreads, sync, sum, min, any) so that the same body runs as one workgroup on the device
-// (gcsadmm.hip terminal_region_kernel) and serially on the host (tests/hostemu/term_emu.cpp).  Work arrays live in the handle's HBM
-// workspace (terminal_ws_doubles): a terminal of degree 40 in R^6 needs 200 KB, more than a CU's LDS, and there are at most two
-// terminals -- this path is latency-bound whatever the storage.
+// Written against an executor EX (tid, nthreads, sync, reduce3; stamp: a no-op outside the timing build) so that the same body runs as one workgroup on the device
+// (terminal_region.hip) and serially on the host (tests/hostemu/term_emu.cpp).  The work arrays (terminal_ws_doubles) are given by the
+// caller: LDS where they fit (a terminal with 6 live edges and 5 facets in R^2: 7 KB), the handle's HBM workspace otherwise (degree 40 in
+// R^6: 200 KB).  The solve is a chain of short dependent phases: it is bound by the latency of its storage and of its barriers, which is
+// why small terminals run in ONE wavefront (barriers and reductions without LDS round trips).
 #pragma once
 #include <stdint.h>
 
@@ -29,6 +30,8 @@ namespace gcs_term {
 
 using gcs_math::rcp;
 using gcs_math::sqrt_nr;
+// a / b and sqrt in the serial (thread 0) parts: refined hardware estimates on the device (gcs_math.h), IEEE on the host
+GCS_HD double fdiv(double a, double b) { return a * rcp(b); }
 
 constexpr double TERM_REG = 1e-7;         // Tikhonov term on every unknown, as in the vertex programs (REG_DELTA)
 constexpr double TERM_CHOL_SKIP = 1e-12;  // pivot floor relative to the diagonal entry, as in the vertex programs
@@ -36,7 +39,7 @@ constexpr double TERM_CHOL_SKIP = 1e-12;  // pivot floor relative to the diagona
 inline long long terminal_ws_doubles(int n, int m, int L)
 {
     const long long NW = 2 * n + 1, R = 2 * m, NF = n + 1;
-    return m + (long long)L * (6 * NW + 5 * R + NW * NW + NW * NF + NF);
+    return m + (long long)m * n + (long long)L * (6 * NW + 5 * R + NW * NW + NW * NF + NF);
 }
 
 template <int N> struct TermShared {
@@ -85,8 +88,9 @@ template <int Q> GCS_HD void soc_div(const double *l, const double *d, double *x
 {   // l o x = d
     double ld1 = 0;
     for (int k = 1; k < Q; ++k) ld1 += l[k] * d[k];
-    x[0] = (l[0] * d[0] - ld1) / gcs_math::soc_det<Q>(l);
-    for (int k = 1; k < Q; ++k) x[k] = (d[k] - x[0] * l[k]) / l[0];
+    x[0] = fdiv(l[0] * d[0] - ld1, gcs_math::soc_det<Q>(l));
+    const double il0 = rcp(l[0]);
+    for (int k = 1; k < Q; ++k) x[k] = (d[k] - x[0] * l[k]) * il0;
 }
 
 // Returns the iteration count (>= 0) or a negative status; every thread of the workgroup returns the same value.
@@ -98,14 +102,15 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
     const int lo = P.is_src ? P.d_in : 0, hi = P.is_src ? P.d : P.d_in, L = hi - lo;
     const int tid = ex.tid(), nt = ex.nthreads();
     if (L <= 0) return -2;
-    double *b = ws, *pp = b + m, *tg = pp + L * NW, *qd = tg + L * NW, *rhs = qd + L * NW, *hr = rhs + L * NW, *dp = hr + L * NW;
+    double *b = ws, *Al = b + m, *pp = Al + m * N, *tg = pp + L * NW, *qd = tg + L * NW, *rhs = qd + L * NW, *hr = rhs + L * NW, *dp = hr + L * NW;
     double *sl = dp + L * NW, *lam = sl + L * R, *kap = lam + L * R, *ds = kap + L * R, *dl = ds + L * R;
     double *H = dl + L * R, *X = H + (size_t)L * NW * NW, *zc = X + (size_t)L * NW * NF;
-    const double *A = P.A;
-    // ---- prologue: raw right-hand sides, targets, the start y_e = 1 / L, O_e = y_e (c, c), t = 1
+    const double *A = Al;
+    // ---- prologue: the facets next to the other work arrays (they are read in every phase: LDS, not HBM, where the arrays are in LDS),
+    //      raw right-hand sides, targets, the start y_e = 1 / L, O_e = y_e (c, c), t = 1
     for (int j = tid; j < m; j += nt) {
         double a = P.bc[j];
-        for (int k = 0; k < N; ++k) a += A[j * N + k] * P.cen[k];
+        for (int k = 0; k < N; ++k) { const double ajk = P.A[j * N + k]; Al[j * N + k] = ajk; a += ajk * P.cen[k]; }
         b[j] = a;
     }
     const double invL = 1.0 / L;
@@ -126,26 +131,41 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
     int it = 0;
     // one Newton solve with the multipliers kap (rows) / sh.ksoc (cone) in place of the duals: leaves dp, ds, sh.dssoc, sh.dt, sh.dnu
     auto newton = [&]() {
-        const double gt = 1.0 - sh.ksoc[0], ct = gt / sh.c0;
-        for (int e = tid; e < L; e += nt) {
-            double *r = rhs + e * NW, *h = hr + e * NW;
-            const double *pe = pp + e * NW, *te = tg + e * NW, *qe = qd + e * NW, *ke = kap + e * R;
-            for (int k = 0; k < NW; ++k) r[k] = -(qe[k] * (pe[k] - te[k]) + TERM_REG * pe[k]);
-            double gy = P.eps_edge + sh.nu;
-            for (int i = 0; i < 2; ++i)
-                for (int j = 0; j < m; ++j) {
-                    const double kv = ke[i * m + j];
-                    for (int k = 0; k < N; ++k) r[i * N + k] -= A[j * N + k] * kv;
-                    gy -= b[j] * kv;
-                }
-            r[2 * N] -= gy;
-            for (int k = 0; k < N; ++k) { const double c = sh.ksoc[1 + k] + sh.cv[k] * ct; r[k] += c; r[N + k] -= c; }
-            const double *Le = H + (size_t)e * NW * NW, *Xe = X + (size_t)e * NW * NF;
-            for (int c = 0; c < NF; ++c) { double a = 0; for (int k = 0; k < NW; ++k) a += Xe[k * NF + c] * r[k]; zc[e * NF + c] = a; }
-            for (int i = 0; i < NW; ++i) { double a = r[i]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * h[k]; h[i] = a / Le[i * NW + i]; }
-            for (int i = NW - 1; i >= 0; --i) { double a = h[i]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * h[k]; h[i] = a / Le[i * NW + i]; }
+        const double gt = 1.0 - sh.ksoc[0], ct = fdiv(gt, sh.c0);
+        // right-hand sides, one entry per thread (sums in registers): -(grad f + G' kap) of the block, the cone's part, t eliminated
+        for (int idx = tid; idx < L * NW; idx += nt) {
+            const int e = idx / NW, k = idx - e * NW;
+            const double *ke = kap + e * R;
+            double a = -(qd[idx] * (pp[idx] - tg[idx]) + TERM_REG * pp[idx]);
+            if (k < 2 * N) {
+                const int i = k < N ? 0 : 1, kk = k - i * N;
+                for (int j = 0; j < m; ++j) a -= A[j * N + kk] * ke[i * m + j];
+                const double c = sh.ksoc[1 + kk] + sh.cv[kk] * ct;
+                a += i == 0 ? c : -c;
+            } else {
+                double gy = P.eps_edge + sh.nu;
+                for (int r = 0; r < R; ++r) gy -= b[r < m ? r : r - m] * ke[r];
+                a -= gy;
+            }
+            rhs[idx] = a;
         }
         ex.sync();
+        ex.stamp(5);       // right-hand sides
+        for (int idx = tid; idx < L * NF; idx += nt) {      // the block's part of z = sum_e X_e' rhs_e
+            const int e = idx / NF, c = idx - e * NF;
+            const double *Xe = X + (size_t)e * NW * NF, *r = rhs + e * NW;
+            double a = 0;
+            for (int k = 0; k < NW; ++k) a += Xe[k * NF + c] * r[k];
+            zc[idx] = a;
+        }
+        for (int e = tid; e < L; e += nt) {                 // H_e^{-1} rhs_e
+            const double *Le = H + (size_t)e * NW * NW, *r = rhs + e * NW;
+            double *h = hr + e * NW;
+            for (int i = 0; i < NW; ++i) { double a = r[i]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * h[k]; h[i] = a * Le[i * NW + i]; }
+            for (int i = NW - 1; i >= 0; --i) { double a = h[i]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * h[k]; h[i] = a * Le[i * NW + i]; }
+        }
+        ex.sync();
+        ex.stamp(6);       // X' rhs, H^{-1} rhs
         for (int c = tid; c < NF; c += nt) { double a = 0; for (int e = 0; e < L; ++e) a += zc[e * NF + c]; sh.z[c] = a; }
         ex.sync();
         if (tid == 0) {       // (I + S_uu Su) du + S_uy dnu = z_u ;  S_yu Su du + S_yy dnu = z_y : Gaussian elimination, partial pivoting
@@ -161,18 +181,20 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
                 for (int r = c + 1; r < NF; ++r) if (fabs(M[r * NF + c]) > fabs(M[piv * NF + c])) piv = r;
                 if (M[piv * NF + c] == 0.0) { singular = true; break; }
                 if (piv != c) { for (int k = 0; k < NF; ++k) { const double tmp = M[c * NF + k]; M[c * NF + k] = M[piv * NF + k]; M[piv * NF + k] = tmp; } const double tmp = x[c]; x[c] = x[piv]; x[piv] = tmp; }
+                const double ipiv = rcp(M[c * NF + c]);
                 for (int r = c + 1; r < NF; ++r) {
-                    const double f = M[r * NF + c] / M[c * NF + c];
+                    const double f = M[r * NF + c] * ipiv;
                     for (int k = c; k < NF; ++k) M[r * NF + k] -= f * M[c * NF + k];
                     x[r] -= f * x[c];
                 }
             }
             if (singular) sh.status = -5;
-            else for (int r = NF - 1; r >= 0; --r) { double a = x[r]; for (int k = r + 1; k < NF; ++k) a -= M[r * NF + k] * x[k]; x[r] = a / M[r * NF + r]; }
+            else for (int r = NF - 1; r >= 0; --r) { double a = x[r]; for (int k = r + 1; k < NF; ++k) a -= M[r * NF + k] * x[k]; x[r] = fdiv(a, M[r * NF + r]); }
             for (int k = 0; k < N; ++k) { double v = 0; for (int l = 0; l < N; ++l) v += sh.Su[k * N + l] * x[l]; sh.su[k] = v; }
             sh.su[N] = x[N]; sh.dnu = x[N];
         }
         ex.sync();
+        ex.stamp(7);       // z, the small system (thread 0)
         for (int idx = tid; idx < L * NW; idx += nt) {
             const int e = idx / NW, k = idx - e * NW;
             const double *Xe = X + (size_t)e * NW * NF;
@@ -192,9 +214,10 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         if (tid == 0) {
             double a = -gt;
             for (int k = 0; k < N; ++k) a -= sh.cv[k] * sh.dssoc[1 + k];
-            sh.dt = a / sh.c0; sh.dssoc[0] = sh.dt;
+            sh.dt = fdiv(a, sh.c0); sh.dssoc[0] = sh.dt;
         }
         ex.sync();
+        ex.stamp(8);       // dp, ds, du, dt
     };
     // the rows of a Newton step: dl = kv - lam - (lam / s) ds; step bound, the two sums of the step-length model; prod: leave ds dl in kap
     auto rows = [&](bool corrector, double &amax, double &c1, double &c2) {
@@ -208,7 +231,8 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
             s1 += sv * dlv + lv * dsv; s2 += dsv * dlv;
             if (!corrector) kap[idx] = dsv * dlv;
         }
-        amax = ex.min(am); c1 = ex.sum(s1); c2 = ex.sum(s2);
+        ex.reduce3(am, s1, s2);       // min, sum, sum over the workgroup in one pass
+        amax = am; c1 = s1; c2 = s2;
     };
     for (it = 0; it <= P.ipm_max_iter; ++it) {
         // ---- slacks, complementarity
@@ -222,10 +246,14 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
             if (!(a > 0)) bad = true;
             if (it == 0) lam[idx] = 1.0 / a;
             gsum += a * lam[idx];
+            dl[idx] = lam[idx] / a;         // the row's weight in the block Hessians (dl is free until the first Newton step)
         }
         for (int k = tid; k < N; k += nt) { double a = 0; for (int e = 0; e < L; ++e) a += pp[e * NW + k] - pp[e * NW + N + k]; sh.ssoc[1 + k] = a; }
-        const double gap_rows = ex.sum(gsum);
-        const bool any_bad = ex.any(bad);
+        double flag = bad ? -1.0 : 1.0, unused = 0.0;
+        ex.reduce3(flag, gsum, unused);
+        const double gap_rows = gsum;
+        const bool any_bad = flag < 0.0;
+        ex.stamp(0);       // slacks + reduction
         if (tid == 0) {
             sh.ssoc[0] = sh.t;
             if (any_bad || !gcs_math::soc_interior<Q>(sh.ssoc)) { sh.status = -3; sh.stop = 1; }
@@ -242,27 +270,28 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
                     const double ss = gcs_math::soc_det<Q>(sh.ssoc), zz = gcs_math::soc_det<Q>(sh.lsoc);
                     if (!(ss > 0.0) || !(zz > 0.0)) { sh.status = sh.mu <= 1e3 * P.ipm_tol ? 0 : -4; sh.stop = 1; }
                     else {
-                        const double is = 1.0 / sqrt(ss), iz = 1.0 / sqrt(zz);
+                        const double is = gcs_math::rsqrt_nr(ss), iz = gcs_math::rsqrt_nr(zz);
                         double dot = 0, wb[Q];
                         for (int k = 0; k < Q; ++k) dot += (sh.ssoc[k] * is) * (sh.lsoc[k] * iz);
-                        const double gam = sqrt(0.5 * (1.0 + dot));
-                        wb[0] = (sh.ssoc[0] * is + sh.lsoc[0] * iz) / (2 * gam);
-                        for (int k = 1; k < Q; ++k) wb[k] = (sh.ssoc[k] * is - sh.lsoc[k] * iz) / (2 * gam);
-                        const double eta = sqrt(sqrt(ss / zz));
+                        const double gam = sqrt_nr(0.5 * (1.0 + dot));
+                        const double i2g = 0.5 * rcp(gam);
+                        wb[0] = (sh.ssoc[0] * is + sh.lsoc[0] * iz) * i2g;
+                        for (int k = 1; k < Q; ++k) wb[k] = (sh.ssoc[k] * is - sh.lsoc[k] * iz) * i2g;
+                        const double eta = sqrt_nr(sqrt_nr(fdiv(ss, zz))), ieta = rcp(eta), iw0 = rcp(1.0 + wb[0]);
                         for (int i = 0; i < Q; ++i)
                             for (int j = 0; j < Q; ++j) {
                                 double w;
                                 if (i == 0 && j == 0) w = wb[0];
                                 else if (i == 0) w = wb[j];
                                 else if (j == 0) w = wb[i];
-                                else w = (i == j ? 1.0 : 0.0) + wb[i] * wb[j] / (1.0 + wb[0]);
+                                else w = (i == j ? 1.0 : 0.0) + wb[i] * wb[j] * iw0;
                                 sh.Wsoc[i * Q + j] = eta * w;
-                                sh.Wsoci[i * Q + j] = (((i == 0) != (j == 0)) ? -w : w) / eta;
+                                sh.Wsoci[i * Q + j] = (((i == 0) != (j == 0)) ? -w : w) * ieta;
                             }
                         for (int i = 0; i < Q; ++i)
                             for (int j = 0; j < Q; ++j) { double a = 0; for (int k = 0; k < Q; ++k) a += sh.Wsoci[i * Q + k] * sh.Wsoci[k * Q + j]; sh.W2[i * Q + j] = a; }
                         for (int i = 0; i < Q; ++i) { double a = 0; for (int k = 0; k < Q; ++k) a += sh.Wsoc[i * Q + k] * sh.lsoc[k]; sh.lt[i] = a; }
-                        const double ie2 = 1.0 / (eta * eta), g2 = 2.0 / (2.0 * wb[0] * wb[0] - 1.0);
+                        const double ie2 = ieta * ieta, g2 = 2.0 * rcp(2.0 * wb[0] * wb[0] - 1.0);
                         sh.c0 = ie2 * (2.0 * wb[0] * wb[0] - 1.0);
                         for (int k = 0; k < N; ++k) sh.cv[k] = -ie2 * 2.0 * wb[0] * wb[1 + k];
                         for (int k = 0; k < N; ++k) for (int l = 0; l < N; ++l) sh.Su[k * N + l] = ie2 * ((k == l ? 1.0 : 0.0) - g2 * wb[1 + k] * wb[1 + l]);
@@ -271,46 +300,55 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
             }
         }
         ex.sync();
+        ex.stamp(1);       // stop test + cone scaling (thread 0)
         if (sh.stop) break;
         // ---- block Hessians  H_e = Q_e + REG + sum_rows (lam / s) g g',  g = (a_j on [O]_i, -b_j on y)
         for (int idx = tid; idx < L * NW * NW; idx += nt) {
             const int e = idx / (NW * NW), ac = idx - e * NW * NW, a = ac / NW, c = ac - a * NW;
             double v = a == c ? qd[e * NW + a] + TERM_REG : 0.0;
             const int ia = a < N ? 0 : (a < 2 * N ? 1 : 2), ic = c < N ? 0 : (c < 2 * N ? 1 : 2);
+            const double *De = dl + e * R;
             if (ia == 2 && ic == 2) {
-                for (int r = 0; r < R; ++r) { const int j = r < m ? r : r - m; v += lam[e * R + r] / sl[e * R + r] * b[j] * b[j]; }
+                for (int r = 0; r < R; ++r) { const int j = r < m ? r : r - m; v += De[r] * b[j] * b[j]; }
             } else if (ia == 2 || ic == 2) {
                 const int i = ia == 2 ? ic : ia, k = (ia == 2 ? c : a) - i * N;
-                for (int j = 0; j < m; ++j) v -= lam[e * R + i * m + j] / sl[e * R + i * m + j] * A[j * N + k] * b[j];
+                for (int j = 0; j < m; ++j) v -= De[i * m + j] * A[j * N + k] * b[j];
             } else if (ia == ic) {
                 const int ka = a - ia * N, kc = c - ia * N;
-                for (int j = 0; j < m; ++j) v += lam[e * R + ia * m + j] / sl[e * R + ia * m + j] * A[j * N + ka] * A[j * N + kc];
+                for (int j = 0; j < m; ++j) v += De[ia * m + j] * A[j * N + ka] * A[j * N + kc];
             }
             H[idx] = v;
         }
         ex.sync();
-        // ---- per block: Cholesky in place (clamped pivots), X = H^{-1} F'
+        ex.stamp(2);       // block Hessians
+        // ---- per block: Cholesky in place (clamped pivots; the diagonal holds 1 / L_jj: the solves multiply), then X = H^{-1} F', one
+        //      (block, column) per thread
         for (int e = tid; e < L; e += nt) {
-            double *Le = H + (size_t)e * NW * NW, *Xe = X + (size_t)e * NW * NF;
+            double *Le = H + (size_t)e * NW * NW;
             for (int j = 0; j < NW; ++j) {
                 const double d0 = Le[j * NW + j];       // (column j is untouched until now: the entry of H itself)
                 double dj = d0;
                 for (int k = 0; k < j; ++k) dj -= Le[j * NW + k] * Le[j * NW + k];
                 if (!(dj > TERM_CHOL_SKIP * d0)) dj = d0 > 0 ? TERM_CHOL_SKIP * d0 : 1.0;
-                dj = sqrt(dj);
-                Le[j * NW + j] = dj;
+                const double inv = 1.0 / sqrt(dj);
+                Le[j * NW + j] = inv;
                 for (int i = j + 1; i < NW; ++i) {
                     double sv = Le[i * NW + j];
                     for (int k = 0; k < j; ++k) sv -= Le[i * NW + k] * Le[j * NW + k];
-                    Le[i * NW + j] = sv / dj;
+                    Le[i * NW + j] = sv * inv;
                 }
             }
-            for (int c = 0; c < NF; ++c) {      // column c of X = H^{-1} F', solved in place
-                for (int k = 0; k < NW; ++k) Xe[k * NF + c] = 0.0;
-                if (c < N) { Xe[c * NF + c] = 1.0; Xe[(N + c) * NF + c] = -1.0; } else Xe[2 * N * NF + c] = 1.0;
-                for (int i = 0; i < NW; ++i) { double a = Xe[i * NF + c]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * Xe[k * NF + c]; Xe[i * NF + c] = a / Le[i * NW + i]; }
-                for (int i = NW - 1; i >= 0; --i) { double a = Xe[i * NF + c]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * Xe[k * NF + c]; Xe[i * NF + c] = a / Le[i * NW + i]; }
-            }
+        }
+        ex.sync();
+        ex.stamp(3);       // Cholesky
+        for (int idx = tid; idx < L * NF; idx += nt) {
+            const int e = idx / NF, c = idx - e * NF;
+            const double *Le = H + (size_t)e * NW * NW;
+            double *Xe = X + (size_t)e * NW * NF;
+            for (int k = 0; k < NW; ++k) Xe[k * NF + c] = 0.0;
+            if (c < N) { Xe[c * NF + c] = 1.0; Xe[(N + c) * NF + c] = -1.0; } else Xe[2 * N * NF + c] = 1.0;
+            for (int i = 0; i < NW; ++i) { double a = Xe[i * NF + c]; for (int k = 0; k < i; ++k) a -= Le[i * NW + k] * Xe[k * NF + c]; Xe[i * NF + c] = a * Le[i * NW + i]; }
+            for (int i = NW - 1; i >= 0; --i) { double a = Xe[i * NF + c]; for (int k = i + 1; k < NW; ++k) a -= Le[k * NW + i] * Xe[k * NF + c]; Xe[i * NF + c] = a * Le[i * NW + i]; }
         }
         ex.sync();
         for (int ac = tid; ac < NF * NF; ac += nt) {      // S = sum_e F X_e
@@ -326,15 +364,17 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         for (int idx = tid; idx < L * R; idx += nt) kap[idx] = 0.0;
         if (tid == 0) for (int k = 0; k < Q; ++k) sh.ksoc[k] = 0.0;
         ex.sync();
+        ex.stamp(4);       // X, S
         newton();
         double amax, c1, c2;
         rows(false, amax, c1, c2);
+        ex.stamp(10);      // rows of the predictor
         if (tid == 0) {
             for (int i = 0; i < Q; ++i) { double a = -sh.lsoc[i]; for (int k = 0; k < Q; ++k) a -= sh.W2[i * Q + k] * sh.dssoc[k]; sh.dlsoc[i] = a; }
             amax = fmin(amax, fmin(gcs_math::soc_max_step<Q>(sh.ssoc, sh.dssoc), gcs_math::soc_max_step<Q>(sh.lsoc, sh.dlsoc)));
             for (int k = 0; k < Q; ++k) { c1 += sh.ssoc[k] * sh.dlsoc[k] + sh.lsoc[k] * sh.dssoc[k]; c2 += sh.dssoc[k] * sh.dlsoc[k]; }
             const double al_aff = fmin(1.0, amax);
-            double sig = (sh.gap + al_aff * c1 + al_aff * al_aff * c2) / deg / sh.mu;
+            double sig = fdiv(sh.gap + al_aff * c1 + al_aff * al_aff * c2, deg * sh.mu);
             sig = sig < 0 ? 0 : (sig > 1 ? 1 : sig);
             sh.sm = sig * sig * sig * sh.mu;
             // cone: kappa = sigma mu s^{-1} - W^{-1} (lt \ ((W^{-1} ds_a) o (W dl_a)))
@@ -346,19 +386,21 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
             }
             soc_prod<Q>(a1, a2, pr);
             soc_div<Q>(sh.lt, pr, qv);
-            const double dets = gcs_math::soc_det<Q>(sh.ssoc);
+            const double idets = rcp(gcs_math::soc_det<Q>(sh.ssoc));
             for (int i = 0; i < Q; ++i) {
                 double a = 0;
                 for (int k = 0; k < Q; ++k) a += sh.Wsoci[i * Q + k] * qv[k];
-                sh.ksoc[i] = sh.sm * (i == 0 ? sh.ssoc[0] : -sh.ssoc[i]) / dets - a;
+                sh.ksoc[i] = sh.sm * (i == 0 ? sh.ssoc[0] : -sh.ssoc[i]) * idets - a;
             }
         }
         ex.sync();
+        ex.stamp(11);      // sigma, cone multipliers (thread 0)
         // ---- corrector
         for (int idx = tid; idx < L * R; idx += nt) kap[idx] = (sh.sm - kap[idx]) / sl[idx];
         ex.sync();
         newton();
         rows(true, amax, c1, c2);
+        ex.stamp(12);      // kappa + rows of the corrector
         if (tid == 0) {
             for (int i = 0; i < Q; ++i) { double a = sh.ksoc[i] - sh.lsoc[i]; for (int k = 0; k < Q; ++k) a -= sh.W2[i * Q + k] * sh.dssoc[k]; sh.dlsoc[i] = a; }
             amax = fmin(amax, fmin(gcs_math::soc_max_step<Q>(sh.ssoc, sh.dssoc), gcs_math::soc_max_step<Q>(sh.lsoc, sh.dlsoc)));
@@ -380,6 +422,7 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         for (int idx = tid; idx < L * NW; idx += nt) pp[idx] += al * dp[idx];
         for (int idx = tid; idx < L * R; idx += nt) lam[idx] += al * dl[idx];
         ex.sync();
+        ex.stamp(13);      // step length (thread 0) + update
     }
     const int status = sh.status;
     if (status != 0) return status < -1 ? status : -1;      // (the copies of a failed solve keep their previous values)

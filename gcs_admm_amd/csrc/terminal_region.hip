@@ -1,4 +1,4 @@
-// terminal_region.hip -- x-update of terminals that are regions (terminal_region.h): one 256-thread workgroup per terminal, launched on
+// terminal_region.hip -- x-update of terminals that are regions (terminal_region.h): one workgroup of 64 or 256 threads per terminal, launched on
 // the handle's auxiliary stream beside the vertex-step launch (gcsadmm.hip launch_vertex).  Own object: the vertex kernels are not touched.
 #include <hip/hip_runtime.h>
 
@@ -10,35 +10,56 @@ namespace gcsadmm_k {
 
 constexpr int TERM_THREADS = 256;
 
-// executor of terminal_region_solve on the device: the workgroup, reductions through LDS in a fixed order (bit-reproducible)
+// executor of terminal_region_solve on the device: one workgroup of 64 or 256 threads; reductions by wavefront shuffles in a fixed order
+// (bit-reproducible), across wavefronts through LDS
+#ifdef GCS_TERM_TIMING
+__device__ unsigned long long g_term_cycles[32], g_term_visits[32];      // diagnostic build: ticks per phase of the solve, workgroup 0
+#endif
 struct TermExec {
-    double *red;      // [TERM_THREADS]
-    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
-    __device__ __forceinline__ int nthreads() const { return TERM_THREADS; }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    template <class OP> __device__ __forceinline__ double reduce(double x, OP op)
+    double *red;      // [3 * 4]
+#ifdef GCS_TERM_TIMING
+    unsigned long long last = 0;
+    __device__ __forceinline__ void stamp(int k)
     {
-        red[threadIdx.x] = x;
-        __syncthreads();
-        for (int off = TERM_THREADS / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) red[threadIdx.x] = op(red[threadIdx.x], red[threadIdx.x + off]);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0 && blockIdx.x == 0 && last) { atomicAdd(&g_term_cycles[k], t - last); atomicAdd(&g_term_visits[k], 1ull); }
+        last = __builtin_amdgcn_s_memtime();
+    }
+#else
+    __device__ __forceinline__ void stamp(int) {}
+#endif
+    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ void reduce3(double &mn, double &s1, double &s2)
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, off, 64));
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+        }
+        const int nw = (int)blockDim.x >> 6;
+        if (nw > 1) {
+            const int w = (int)threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { red[w] = mn; red[4 + w] = s1; red[8 + w] = s2; }
+            __syncthreads();
+            mn = red[0]; s1 = red[4]; s2 = red[8];
+            for (int k = 1; k < nw; ++k) { mn = fmin(mn, red[k]); s1 += red[4 + k]; s2 += red[8 + k]; }
             __syncthreads();
         }
-        const double r = red[0];
-        __syncthreads();
-        return r;
     }
-    __device__ __forceinline__ double sum(double x) { return reduce(x, [](double a, double b) { return a + b; }); }
-    __device__ __forceinline__ double min(double x) { return reduce(x, [](double a, double b) { return fmin(a, b); }); }
-    __device__ __forceinline__ bool any(bool b) { return __syncthreads_or(b ? 1 : 0) != 0; }
 };
 
-template <int N, class T>
+// LDSWS: the work arrays live in dynamic LDS (its own instantiation, so that the compiler addresses them as LDS rather than through flat pointers)
+template <int N, class T, bool LDSWS>
 __global__ __launch_bounds__(TERM_THREADS) void terminal_region_kernel(TermLaunchDesc d)
 {
+    extern __shared__ __attribute__((aligned(16))) double term_lds[];
     if (d.cb->status != GCSADMM_RUNNING) return;
     __shared__ gcs_term::TermShared<N> sh;
-    __shared__ double red[TERM_THREADS];
+    __shared__ double red[12];
     const int ti = (int)blockIdx.x, v = d.vtx[ti];
     gcs_term::TermProblem<T> P;
     const int p0 = d.poly_ptr[v], lo = d.inc_ptr[v];
@@ -50,7 +71,10 @@ __global__ __launch_bounds__(TERM_THREADS) void terminal_region_kernel(TermLaunc
     P.xv = d.xv + (size_t)v * 2 * N; P.zv = d.zv + (size_t)v * 2 * N; P.yv = d.yv + v;
     P.rho = d.cb->rho; P.mu_scale = d.cb->mu_scale; P.eps_edge = d.eps_edge; P.ipm_tol = d.ipm_tol; P.ipm_max_iter = d.ipm_max_iter;
     TermExec ex{red};
-    const int r = gcs_term::terminal_region_solve<N, T>(ex, P, d.ws + d.ws_off[ti], sh);
+    // work arrays: LDS when the launch was given room for the larger of the terminals (d.lds_doubles), the HBM workspace otherwise
+    int r;
+    if constexpr (LDSWS) r = gcs_term::terminal_region_solve<N, T>(ex, P, term_lds, sh);
+    else r = gcs_term::terminal_region_solve<N, T>(ex, P, d.ws + d.ws_off[ti], sh);
     if (threadIdx.x == 0) {
         if (r < 0) atomicAdd(&d.counters[0], 1);
         else atomicAdd(&d.counters[1], r);
@@ -59,11 +83,26 @@ __global__ __launch_bounds__(TERM_THREADS) void terminal_region_kernel(TermLaunc
 
 template <int N> static void launch_n(const TermLaunchDesc &d, hipStream_t s)
 {
-    if (d.dtype == GCSADMM_F64) hipLaunchKernelGGL((terminal_region_kernel<N, double>), dim3(d.count), dim3(TERM_THREADS), 0, s, d);
-    else hipLaunchKernelGGL((terminal_region_kernel<N, float>), dim3(d.count), dim3(TERM_THREADS), 0, s, d);
+    const size_t lds = (size_t)d.lds_doubles * sizeof(double);
+    if (d.dtype == GCSADMM_F64) {
+        if (lds) hipLaunchKernelGGL((terminal_region_kernel<N, double, true>), dim3(d.count), dim3(d.threads), lds, s, d);
+        else hipLaunchKernelGGL((terminal_region_kernel<N, double, false>), dim3(d.count), dim3(d.threads), 0, s, d);
+    } else {
+        if (lds) hipLaunchKernelGGL((terminal_region_kernel<N, float, true>), dim3(d.count), dim3(d.threads), lds, s, d);
+        else hipLaunchKernelGGL((terminal_region_kernel<N, float, false>), dim3(d.count), dim3(d.threads), 0, s, d);
+    }
 }
 
 }  // namespace gcsadmm_k
+
+#ifdef GCS_TERM_TIMING
+extern "C" int gcsadmm_debug_term_cycles(unsigned long long *cycles32, unsigned long long *visits32)
+{
+    int e = (int)hipMemcpyFromSymbol(cycles32, HIP_SYMBOL(gcsadmm_k::g_term_cycles), 32 * sizeof(unsigned long long));
+    if (e == 0) e = (int)hipMemcpyFromSymbol(visits32, HIP_SYMBOL(gcsadmm_k::g_term_visits), 32 * sizeof(unsigned long long));
+    return e;
+}
+#endif
 
 long long gcsadmm_terminal_ws_doubles(int n, int facets, int live_edges) { return gcs_term::terminal_ws_doubles(n, facets, live_edges); }
 

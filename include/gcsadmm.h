@@ -67,7 +67,9 @@ typedef struct gcsadmm_graph_desc {
     const double *poly_A;            /* [poly_ptr[V]][n] facet normals, A x <= b */
     const double *poly_b;            /* [poly_ptr[V]] */
     const double *center;            /* [V][n] a strictly interior point of each polytope */
-    int32_t src, dst;                /* local vertex ids of 's' and 't' (-1 if not in this partition) */
+    int32_t src, dst;                /* local vertex ids of 's' and 't' (-1 if not in this partition).  A terminal whose polytope lies within
+                                        1e-5 of its `center` is a point (utils.py:12-28; closed form); one with an extent is a region and is
+                                        constrained like any set (admm_solver_v3.py:415-464): own kernel, needs an edge on its live side */
     int32_t state_dtype;             /* GCSADMM_F64 / GCSADMM_F32 */
     int32_t device;                  /* HIP device ordinal */
     const uint8_t *inc_counted;      /* [NI] or NULL(=all 1): this handle owns the copy (counts it in the norms) */
@@ -195,7 +197,7 @@ gcsadmm_status gcsadmm_run_timed(gcsadmm_handle h, const gcsadmm_state *st, int3
  *     s.t. A z_i <= y_v b,  A (x_i - z_i) <= (1 - y_v) b  (:371-381),  0 <= y_v <= 1  (:346).
  * Same interior-point method and kernel as the v3 vertex step (workgroup program, "prox" configuration).  q_dev, c_dev:
  * [V][4n+1] f64 device arrays (weights >= 0, not all zero per vertex; centres); outputs [V][2n], [V][2n], [V] f64 device arrays.
- * The two terminals are points (closed form).  failures_host (may be NULL; non-NULL synchronises the stream) receives the
+ * The two terminals are points (closed form; a graph with a terminal that is a region is refused here).  failures_host (may be NULL; non-NULL synchronises the stream) receives the
  * number of inner solves that did not converge (their outputs are left untouched).  The edge side of those splittings -- one
  * monolithic conic program over all edges (v1) or a sequential sweep (v2) -- is out of scope.
  */

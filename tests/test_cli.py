@@ -120,3 +120,28 @@ def test_cli_runs_a_graph_file(tmp_path):
     gold = case["golden_v3"]
     assert rec["iterations"] == gold["iterations"] == 39 and abs(rec["cost"] - gold["cost"]) <= 2e-4
     assert list(rec["As"]) == g.keys
+
+
+@pytest.mark.gpu
+def test_cli_runs_a_case_whose_terminals_are_regions(tmp_path):
+    """the reference's case format lets 's' / 't' be any polytope (test_data/*.py build them with convert_pt_to_polytope, utils.py:12-28,
+    but admm_solver_v3.py:415-464 constrains them like every set): three boxes in a row, the outer two are the terminals.  Loop, rounding
+    and record through the command line; the rounded path leaves s and enters t at the facing sides, length 1 (point terminals at the
+    box centres would give 2)."""
+    lines = ["import numpy as np", "n = 2", "A = np.vstack([np.eye(2), -np.eye(2)])",
+             "As = {'s': A, 't': A, 0: A}",
+             "bs = {'s': np.array([1.0, 1.0, 0.0, 0.0]), 't': np.array([3.0, 1.0, -2.0, 0.0]), 0: np.array([2.2, 1.0, -0.8, 0.0])}"]
+    case_dir = tmp_path / "cases"; case_dir.mkdir()
+    (case_dir / "region_row.py").write_text("\n".join(lines) + "\n")
+    env = dict(os.environ, PYTHONPATH=str(case_dir) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "admm_solver_v3.py"), "--test_file", "region_row", "--show_plot", "False"],
+                       capture_output=True, text=True, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "BREAKING FOR OPT" in r.stdout and "Inner solver failures: 0" in r.stdout
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pkl_reader import load_data
+    rec = load_data(str(tmp_path / "benchmark_data" / "admm_solver_v3_region_row.pkl"))
+    assert abs(rec["cost"] - 1.0002) < 1e-2
+    assert all(rec["y_v_rounded"][v] == 1 for v in ("s", 0, "t"))
+    length = sum(float(np.linalg.norm(np.asarray(rec["x_v_rounded"][v])[:2] - np.asarray(rec["x_v_rounded"][v])[2:])) for v in ("s", 0, "t"))
+    assert abs(length - 1.0) < 1e-5
