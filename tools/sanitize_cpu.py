@@ -53,3 +53,22 @@ from gcs_admm_amd.graph import lattice_boxes
 for name in ('benchmark1','benchmark4'):
     case,g=load_fixture(name); r=O.Oracle(g,ipm_tol=IPM_TOL).run(nthreads=2); print(name,r['iterations'])
 g=lattice_boxes(5,4,n=6,seed=1); r=O.Oracle(g,ipm_tol=IPM_TOL).run(max_it=5,eps_abs=0,eps_rel=0,nthreads=2); print('n6',r['iterations'])
+
+# ---- terminals that are regions: the device body's host build and the oracle's restatement (both under the sanitizers)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import test_terminal_region as TR
+term = C.CDLL('/tmp/libtermemu_asan.so')
+for n, seed in [(2, 0), (2, 1), (1, 4), (3, 5), (6, 7)]:
+    rng = np.random.default_rng(100 + seed)
+    cen = rng.uniform(-1, 1, n)
+    A, b = TR.polygon(rng, 3 + seed % 4, cen, 0.6) if n == 2 else TR.box_in(rng, n, cen, 0.5)
+    d_in, d_out = 1 + seed % 3, 2 + seed % 4
+    T = np.zeros((2 * n + 1, d_in + d_out)); T[:2 * n] = 0.35 * rng.normal(size=(2 * n, d_in + d_out)); T[2 * n] = rng.uniform(-0.1, 0.8, d_in + d_out)
+    e = TR.emu_terminal(term, n, A, b, cen, d_in + d_out, d_in, seed % 2 == 0, T, 1.0)
+    lib_o = O._lib
+    ip = O._Inner(1e-4, IPM_TOL, 60, None, None)
+    copy = np.zeros((2 * n + 1, d_in + d_out)); xv = np.zeros(2 * n); zv = np.zeros(2 * n); yv = np.zeros(1)
+    r = lib_o.oracle_solve_vertex(n, A.shape[0], p(A), p(b), p(cen), d_in + d_out, d_in, int(seed % 2 == 0), int(seed % 2 != 0), p(T), C.c_double(1.0),
+                                  C.byref(ip), p(copy), p(xv), p(zv), p(yv), None)
+    assert r >= 0 and np.abs(copy - e[0]).max() < 2e-5
+    print('region terminal n =', n, 'ok')
