@@ -301,6 +301,49 @@ def test_region_terminals_whole_run(torch_gpu, oracle_lib):
         d2.close()
 
 
+def test_region_terminals_on_a_vertex_partition(torch_gpu):
+    """a lattice whose terminals are boxes of half-width 0.3, as three row strips (three handles on one GPU, halo columns copied by hand,
+    norms summed) against the single handle: the strip that owns a terminal launches the terminal kernel, the others do not; same stop
+    decisions, sums to 1e-9, edge copies to 1e-8 (f64)"""
+    torch = torch_gpu
+    from gcs_admm_amd.partition import build_partition, strip_owner
+    from gcs_admm_amd.solver import DeviceSolver
+    g = lattice_boxes(12, 11, seed=4)
+    for v in (g.src, g.dst):
+        g.poly_b[g.poly_ptr[v]:g.poly_ptr[v + 1]] += 0.3
+    world = 3
+    single = _solver(g)
+    single.reset(max_it=60)
+    owner = strip_owner(g, world)
+    parts = [build_partition(g, owner, r, world) for r in range(world)]
+    devs = [DeviceSolver(p.graph, "f64", device=0, num_incidences=p.num_incidences, inc_counted=p.inc_counted,
+                         edge_counted=p.edge_counted, nx_global=p.nx_global, nmu_global=p.nmu_global) for p in parts]
+    for d in devs:
+        d.reset(max_it=60)
+    idx = {(r, o): (torch.as_tensor(parts[r].recv_idx[o], device="cuda"), torch.as_tensor(parts[o].send_idx[r], device="cuda"))
+           for r in range(world) for o in parts[r].recv_idx}
+    for it in range(20):
+        single.vertex_step(); s_ref = single.edge_step().clone(); single.control()
+        for d in devs:
+            d.vertex_step()
+        for (r, o), (rix, six) in idx.items():
+            devs[r].copy.index_copy_(1, rix, devs[o].copy.index_select(1, six))
+        tot = torch.zeros(5, dtype=torch.float64, device="cuda")
+        for d in devs:
+            tot += d.edge_step()
+        assert torch.allclose(tot, s_ref, rtol=1e-9, atol=1e-12), (it, tot, s_ref)
+        for d in devs:
+            d.control(tot)
+    cbs = [d.read_control() for d in devs] + [single.read_control()]
+    assert len({cb.it for cb in cbs}) == 1 and len({cb.status for cb in cbs}) == 1 and all(cb.inner_failures == 0 for cb in cbs)
+    assert single.yv[g.src].item() == 1.0 and single.yv[g.dst].item() == 1.0
+    xs = single.xv[g.src].cpu().numpy()
+    assert np.abs(xs[:2] - g.interior[g.src]).max() <= 0.3 + 2e-6 and np.abs(xs[:2] - g.interior[g.src]).max() > 1e-3      # inside the box (0.3 + the 1e-6 it had), off its centre
+    full = single.zedge.cpu().numpy()
+    for p, d in zip(parts, devs):
+        assert np.allclose(d.zedge.cpu().numpy(), full[:, p.edge_global], rtol=0, atol=1e-8)
+
+
 def test_region_terminal_refusals(torch_gpu):
     """a region terminal with no edge on its live side cannot carry the unit of flow (the reference's program is infeasible there):
     refused at create; the prox kernel (v1 x-update) keeps point terminals"""
