@@ -395,8 +395,9 @@ struct gcsadmm_handle_s {
     hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
     // terminals that are regions (terminal_region.h): at most two, one workgroup each, on an auxiliary stream beside the vertex-step launch
     int n_term = 0, term_vtx[2] = {-1, -1}, term_is_src[2] = {0, 0};
-    long long term_ws_off[2] = {0, 0};
-    double *d_term_ws = nullptr;
+    long long term_ws_off[2] = {0, 0}, term_rec_off[2] = {0, 0};
+    double *d_term_ws = nullptr, *d_term_rec = nullptr;      // work arrays (when they do not fit LDS); warm-start records
+    size_t term_rec_doubles = 0;
     int term_threads = 256, term_lds_doubles = 0;     // launch shape: one wavefront and LDS work arrays for small terminals
     hipStream_t term_stream = nullptr;
     hipEvent_t ev_term_fork = nullptr, ev_term_join = nullptr;
@@ -530,6 +531,8 @@ static gcsadmm_k::TermLaunchDesc make_term_desc(gcsadmm_handle h, const gcsadmm_
     d.n = h->n; d.dtype = h->dtype; d.count = h->n_term;
     for (int i = 0; i < 2; ++i) { d.vtx[i] = h->term_vtx[i]; d.is_src[i] = h->term_is_src[i]; d.ws_off[i] = h->term_ws_off[i]; }
     d.ws = h->d_term_ws; d.threads = h->term_threads; d.lds_doubles = h->term_lds_doubles;
+    d.rec = h->params.cold_start ? nullptr : h->d_term_rec;
+    for (int i = 0; i < 2; ++i) d.rec_off[i] = h->term_rec_off[i];
     d.inc_ptr = h->d_inc_ptr; d.deg_in = h->d_deg_in; d.inc_edge = h->d_inc_edge; d.poly_ptr = h->d_poly_ptr;
     d.poly_A = h->d_poly_A; d.poly_bc = h->d_poly_bc; d.center = h->d_center;
     d.E = h->E; d.NI = h->NI; d.edge_major = h->edge_major;
@@ -798,6 +801,7 @@ void gcsadmm_destroy(gcsadmm_handle h)
     halo_free(h);
     overlap_free(h);
     if (h->d_term_ws) (void)hipFree(h->d_term_ws);
+    if (h->d_term_rec) (void)hipFree(h->d_term_rec);
     if (h->ev_term_fork) (void)hipEventDestroy(h->ev_term_fork);
     if (h->ev_term_join) (void)hipEventDestroy(h->ev_term_join);
     if (h->term_stream) (void)hipStreamDestroy(h->term_stream);
@@ -1062,13 +1066,14 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     UP(d_sums, (const double *)nullptr, 5);
     UP(d_ticket, (const unsigned *)nullptr, 1);
     if (n_term > 0) {       // region terminals: workspace, an auxiliary stream and the fork / join events
-        long long off = 0, largest = 0;
+        long long off = 0, largest = 0, roff = 0;
         int rows = 0;
         for (int i = 0; i < n_term; ++i) {
             const int v = term_vtx[i], d = g->inc_ptr[v + 1] - g->inc_ptr[v], din = deg_in[v], live = term_is_src[i] ? d - din : din;
             const long long need = gcsadmm_terminal_ws_doubles(n, g->poly_ptr[v + 1] - g->poly_ptr[v], live);
             h->term_vtx[i] = v; h->term_is_src[i] = term_is_src[i]; h->term_ws_off[i] = off;
             off += need; largest = std::max(largest, need);
+            h->term_rec_off[i] = roff; roff += gcsadmm_terminal_record_doubles(n, g->poly_ptr[v + 1] - g->poly_ptr[v], live);
             rows = std::max(rows, live * 2 * (g->poly_ptr[v + 1] - g->poly_ptr[v]));
         }
         h->n_term = n_term;
@@ -1077,6 +1082,8 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
         h->term_lds_doubles = largest * 8 <= 48 * 1024 ? (int)largest : 0;
         h->term_threads = rows <= 256 ? 64 : 256;
         UP(d_term_ws, (const double *)nullptr, (size_t)off);
+        h->term_rec_doubles = (size_t)roff;
+        UP(d_term_rec, (const double *)nullptr, (size_t)roff);
         if ((e = hipStreamCreateWithFlags(&h->term_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
         if ((e = hipEventCreateWithFlags(&h->ev_term_fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&h->ev_term_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -1131,6 +1138,7 @@ gcsadmm_status gcsadmm_reset(gcsadmm_handle h, const gcsadmm_params *p, void *st
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(int), (hipStream_t)stream));
     // a new run starts without warm-start records (runs from the same state are then identical, whatever ran before)
     if (h->warm_doubles > 0) HIPCHK(h, hipMemsetAsync(h->d_warm, 0, h->warm_doubles * sizeof(double), (hipStream_t)stream));
+    if (h->term_rec_doubles > 0) HIPCHK(h, hipMemsetAsync(h->d_term_rec, 0, h->term_rec_doubles * sizeof(double), (hipStream_t)stream));
     h->vertex_steps = 0;
     if (h->d_split_order) HIPCHK(h, hipMemcpyAsync(h->d_split_order, h->d_split_ids, sizeof(int) * (size_t)h->n_waves, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     for (auto po : {std::make_pair(h->d_wave_order, h->n_waves), std::make_pair(h->d_wg_order, h->n_wg)})

@@ -11,7 +11,8 @@
 //   min  t + sum_e [ eps y_e + rho/2 ( |[O_e]_1 - T1_e|^2 + out_e |[O_e]_2 - T2_e|^2 + (y_e - Ty_e)^2 ) ]
 //   s.t. A [O_e]_i <= y_e b (i = 1, 2),   sum_e y_e = 1,   | sum_e ([O_e]_1 - [O_e]_2) | <= t.
 // Same primal-dual method as the generic vertex programs (Mehrotra predictor-corrector, one step length, NT scaling of the cone with t
-// eliminated in closed form, sigma = (mu_aff / mu)^3, stop on mu), cold from y_e = 1 / L, O_e = y_e (c, c) every time.  The Hessian is block
+// eliminated in closed form, sigma = (mu_aff / mu)^3, stop on mu), cold from y_e = 1 / L, O_e = y_e (c, c), or warm from the record the terminal's
+// previous solve left (below: the rule of warm_start.h with a fixed threshold; 7.6 -> ~3.8 Newton iterations per solve).  The Hessian is block
 // diagonal (2n+1 per live block) plus the cone and the equality, which enter through F = [I, -I, 0; 0, 0, 1]: the blocks are eliminated
 // onto (du, dnu), n + 1 unknowns.  The CPU restatement is oracle/gcs_oracle.c solve_terminal_region (checked there against the
 // sub-problem as written, tests/test_terminal_region.py).
@@ -35,6 +36,12 @@ GCS_HD double fdiv(double a, double b) { return a * rcp(b); }
 
 constexpr double TERM_REG = 1e-7;         // Tikhonov term on every unknown, as in the vertex programs (REG_DELTA)
 constexpr double TERM_CHOL_SKIP = 1e-12;  // pivot floor relative to the diagonal entry, as in the vertex programs
+// warm start: the rule and the constants of the vertex programs (warm_start.h) with a fixed threshold.  Record of a terminal, in doubles:
+//   [0] valid [1] rho [2] live blocks [3] nu | per live block: p (2n+1) | targets (2n+1) | row duals (2m)
+// (t and the cone's dual are re-centred at the restart: t^2 - mu_ref t - |u|^2 = 0, lambda = (1, -u / t); not kept)
+constexpr double TERM_WS_KAPPA = 3e-3, TERM_WS_MU_MIN = 1e-7, TERM_WS_COLD_DT = 1.0, TERM_WS_SAVE = 10.0, TERM_WS_COLD_REF = 1e-4;
+constexpr int TERM_W_HDR = 4;
+inline long long terminal_record_doubles(int n, int m, int L) { return TERM_W_HDR + (long long)L * (2 * (2 * n + 1) + 2 * m); }
 
 inline long long terminal_ws_doubles(int n, int m, int L)
 {
@@ -48,8 +55,8 @@ template <int N> struct TermShared {
     double Wsoc[Q * Q], Wsoci[Q * Q], W2[Q * Q], Su[N * N], cv[N];
     double S[NF * NF], z[NF], su[NF];
     double M[NF * NF], x[NF];         // the small system of a Newton solve (thread 0; dynamic row swaps: kept out of registers)
-    double c0, t, nu, dt, dnu, mu, gap, sm, al;
-    int status, stalled, stop;
+    double c0, t, nu, dt, dnu, mu, gap, sm, al, mu_ref;
+    int status, stalled, stop, use_warm, saved, save_now;
 };
 
 // everything the solve reads and writes besides its workspace
@@ -64,6 +71,7 @@ template <class T> struct TermProblem {
     double *xv, *zv, *yv;               // rows of this vertex
     double rho, mu_scale, eps_edge, ipm_tol;
     int ipm_max_iter;
+    double *warm;                       // the terminal's record (terminal_record_doubles, zero = none yet); nullptr: every solve starts cold
 };
 
 template <int N, class T>
@@ -114,21 +122,54 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         b[j] = a;
     }
     const double invL = 1.0 / L;
+    const int W_PER = 2 * NW + R;
+    double *const rec = P.warm;
+    const bool comparable = rec != nullptr && rec[0] == 1.0 && rec[1] == P.rho && (int)rec[2] == L;
+    double moved = 0.0;         // largest |target - target of the record| over the penalised words
     for (int idx = tid; idx < L * NW; idx += nt) {
         const int e = idx / NW, k = idx - e * NW, ge = lo + e;
-        double tgt, q, p0;
-        if (k < N) { tgt = target<N, T>(P, P.is_src ? k : N + k, ge); q = P.rho; p0 = P.cen[k] * invL; }
-        else if (k < 2 * N) { tgt = P.is_src ? target<N, T>(P, k, ge) : 0.0; q = P.is_src ? P.rho : 0.0; p0 = P.cen[k - N] * invL; }
-        else { tgt = target<N, T>(P, 2 * N, ge); q = P.rho; p0 = invL; }
-        tg[idx] = tgt; qd[idx] = q; pp[idx] = p0;
+        double tgt, q;
+        if (k < N) { tgt = target<N, T>(P, P.is_src ? k : N + k, ge); q = P.rho; }
+        else if (k < 2 * N) { tgt = P.is_src ? target<N, T>(P, k, ge) : 0.0; q = P.is_src ? P.rho : 0.0; }
+        else { tgt = target<N, T>(P, 2 * N, ge); q = P.rho; }
+        tg[idx] = tgt; qd[idx] = q;
+        if (comparable && q > 0) moved = fmax(moved, fabs(tgt - rec[TERM_W_HDR + e * W_PER + NW + k]));
     }
-    if (tid == 0) {
-        sh.t = 1.0; sh.nu = 0.0; sh.status = -1; sh.stalled = 0; sh.stop = 0;
-        for (int k = 0; k < Q; ++k) sh.lsoc[k] = 0.0;
+    {
+        double neg = -moved, u1 = 0.0, u2 = 0.0;
+        ex.reduce3(neg, u1, u2);
+        const double dT = -neg * P.rho;
+        if (tid == 0) {
+            sh.use_warm = comparable && dT <= TERM_WS_COLD_DT;
+            sh.mu_ref = sh.use_warm ? fmax(TERM_WS_MU_MIN, TERM_WS_KAPPA * dT) : TERM_WS_COLD_REF;
+        }
     }
     ex.sync();
     const int deg = L * R + 1;
-    int it = 0;
+    int it = 0, it_total = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {          // a warm solve that fails is repeated cold
+    const bool use_warm = sh.use_warm != 0;
+    // ---- the start: the record (cone pair re-centred at mu_ref), or y_e = 1 / L, O_e = y_e (c, c), t = 1
+    if (use_warm) {
+        for (int idx = tid; idx < L * NW; idx += nt) { const int e = idx / NW, k = idx - e * NW; pp[idx] = rec[TERM_W_HDR + e * W_PER + k]; }
+        for (int idx = tid; idx < L * R; idx += nt) { const int e = idx / R, r = idx - e * R; lam[idx] = rec[TERM_W_HDR + e * W_PER + 2 * NW + r]; }
+    } else {
+        for (int idx = tid; idx < L * NW; idx += nt) { const int k = idx % NW; pp[idx] = k < 2 * N ? P.cen[k < N ? k : k - N] * invL : invL; }
+    }
+    ex.sync();
+    if (tid == 0) {
+        sh.status = -1; sh.stalled = 0; sh.stop = 0; sh.saved = 0; sh.save_now = 0;
+        for (int k = 0; k < Q; ++k) sh.lsoc[k] = 0.0;
+        if (use_warm) {
+            double u[N], uu = 0;
+            for (int k = 0; k < N; ++k) { double a = 0; for (int e = 0; e < L; ++e) a += pp[e * NW + k] - pp[e * NW + N + k]; u[k] = a; uu += a * a; }
+            sh.t = 0.5 * (sh.mu_ref + sqrt(sh.mu_ref * sh.mu_ref + 4.0 * uu));
+            sh.lsoc[0] = 1.0;
+            for (int k = 0; k < N; ++k) sh.lsoc[1 + k] = -u[k] / sh.t;
+            sh.nu = rec[3];
+        } else { sh.t = 1.0; sh.nu = 0.0; sh.mu_ref = TERM_WS_COLD_REF; }
+    }
+    ex.sync();
     // one Newton solve with the multipliers kap (rows) / sh.ksoc (cone) in place of the duals: leaves dp, ds, sh.dssoc, sh.dt, sh.dnu
     auto newton = [&]() {
         const double gt = 1.0 - sh.ksoc[0], ct = fdiv(gt, sh.c0);
@@ -235,6 +276,7 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         amax = am; c1 = s1; c2 = s2;
     };
     for (it = 0; it <= P.ipm_max_iter; ++it) {
+        const bool first_warm = use_warm && it == 0;       // the re-centring Newton step of a warm solve: no predictor, no stop test
         // ---- slacks, complementarity
         double gsum = 0;
         bool bad = false;
@@ -244,7 +286,7 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
             for (int k = 0; k < N; ++k) a -= A[j * N + k] * pp[e * NW + i * N + k];
             sl[idx] = a;
             if (!(a > 0)) bad = true;
-            if (it == 0) lam[idx] = 1.0 / a;
+            if (it == 0 && !use_warm) lam[idx] = 1.0 / a;
             gsum += a * lam[idx];
             dl[idx] = lam[idx] / a;         // the row's weight in the block Hessians (dl is free until the first Newton step)
         }
@@ -258,17 +300,23 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
             sh.ssoc[0] = sh.t;
             if (any_bad || !gcs_math::soc_interior<Q>(sh.ssoc)) { sh.status = -3; sh.stop = 1; }
             else {
-                if (it == 0) sh.lsoc[0] = 1.0 / sh.t;
+                if (it == 0 && !use_warm) sh.lsoc[0] = 1.0 / sh.t;
                 double gap = gap_rows;
                 for (int k = 0; k < Q; ++k) gap += sh.ssoc[k] * sh.lsoc[k];
                 sh.gap = gap; sh.mu = gap / deg;
-                if (sh.mu <= P.ipm_tol || (sh.stalled && sh.mu <= 1e3 * P.ipm_tol)) { sh.status = 0; sh.stop = 1; }
+                // the record the next solve restarts from: the first iterate, after at least one Newton step, with mu <= SAVE * mu_ref
+                sh.save_now = rec != nullptr && !sh.saved && it >= 1 && sh.mu <= TERM_WS_SAVE * sh.mu_ref;
+                if (sh.save_now) { sh.saved = 1; rec[0] = 1.0; rec[1] = P.rho; rec[2] = (double)L; rec[3] = sh.nu; }
+                if (!first_warm && (sh.mu <= P.ipm_tol || (sh.stalled && sh.mu <= 1e3 * P.ipm_tol))) {
+                    sh.status = (use_warm && !(sh.mu <= P.ipm_tol)) ? -7 : 0;      // (a warm solve does not leave through the precision-exhausted rule)
+                    sh.stop = 1;
+                }
                 else if (it == P.ipm_max_iter) sh.stop = 1;
                 else {
                     // Nesterov-Todd scaling of the cone pair, W^{-2}, the scaled point; t eliminated in closed form:
                     // W^{-2} = [c0 cv'; cv Mu],  Su = Mu - cv cv' / c0 = eta^-2 (I - 2 wb1 wb1' / (2 wb0^2 - 1))
                     const double ss = gcs_math::soc_det<Q>(sh.ssoc), zz = gcs_math::soc_det<Q>(sh.lsoc);
-                    if (!(ss > 0.0) || !(zz > 0.0)) { sh.status = sh.mu <= 1e3 * P.ipm_tol ? 0 : -4; sh.stop = 1; }
+                    if (!(ss > 0.0) || !(zz > 0.0)) { sh.status = (sh.mu <= 1e3 * P.ipm_tol && !use_warm) ? 0 : -4; sh.stop = 1; }
                     else {
                         const double is = gcs_math::rsqrt_nr(ss), iz = gcs_math::rsqrt_nr(zz);
                         double dot = 0, wb[Q];
@@ -301,6 +349,10 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         }
         ex.sync();
         ex.stamp(1);       // stop test + cone scaling (thread 0)
+        if (sh.save_now) {
+            for (int idx = tid; idx < L * NW; idx += nt) { const int e = idx / NW, k = idx - e * NW; double *w = rec + TERM_W_HDR + e * W_PER; w[k] = pp[idx]; w[NW + k] = tg[idx]; }
+            for (int idx = tid; idx < L * R; idx += nt) { const int e = idx / R, r = idx - e * R; rec[TERM_W_HDR + e * W_PER + 2 * NW + r] = lam[idx]; }
+        }
         if (sh.stop) break;
         // ---- block Hessians  H_e = Q_e + REG + sum_rows (lam / s) g g',  g = (a_j on [O]_i, -b_j on y)
         for (int idx = tid; idx < L * NW * NW; idx += nt) {
@@ -365,8 +417,15 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         if (tid == 0) for (int k = 0; k < Q; ++k) sh.ksoc[k] = 0.0;
         ex.sync();
         ex.stamp(4);       // X, S
-        newton();
         double amax, c1, c2;
+        if (first_warm) {          // kappa = mu_ref / s, the cone's = mu_ref s^{-1}: no predictor, no second-order term
+            if (tid == 0) {
+                sh.sm = sh.mu_ref;
+                const double idets = rcp(gcs_math::soc_det<Q>(sh.ssoc));
+                for (int i = 0; i < Q; ++i) sh.ksoc[i] = sh.sm * (i == 0 ? sh.ssoc[0] : -sh.ssoc[i]) * idets;
+            }
+        } else {
+        newton();
         rows(false, amax, c1, c2);
         ex.stamp(10);      // rows of the predictor
         if (tid == 0) {
@@ -392,6 +451,7 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
                 for (int k = 0; k < Q; ++k) a += sh.Wsoci[i * Q + k] * qv[k];
                 sh.ksoc[i] = sh.sm * (i == 0 ? sh.ssoc[0] : -sh.ssoc[i]) * idets - a;
             }
+        }
         }
         ex.sync();
         ex.stamp(11);      // sigma, cone multipliers (thread 0)
@@ -424,6 +484,17 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         ex.sync();
         ex.stamp(13);      // step length (thread 0) + update
     }
+    it_total += it;
+    ex.sync();
+    const bool failed = sh.status != 0;
+    ex.sync();
+    if (tid == 0 && failed) {
+        if (rec != nullptr) rec[0] = 0.0;      // no restart from a solve that failed
+        sh.use_warm = 0;
+    }
+    ex.sync();
+    if (!failed || !use_warm) break;
+  }
     const int status = sh.status;
     if (status != 0) return status < -1 ? status : -1;      // (the copies of a failed solve keep their previous values)
     // ---- outputs: copies of every incidence (the dead side: y = 0, O = 0; the free word of an incoming edge sits at its target), x = z = sum O, y_v = 1
@@ -443,7 +514,7 @@ GCS_HD int terminal_region_solve(EX &ex, const TermProblem<T> &P, double *ws, Te
         P.xv[k] = a; P.zv[k] = a;
     }
     if (tid == 0) P.yv[0] = 1.0;
-    return it;
+    return it_total;
 }
 
 }  // namespace gcs_term

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(TERM_THREADS) void terminal_region_kernel(TermLaunc
     P.zedge = (const T *)d.zedge; P.mu = (const T *)d.mu; P.copy = (T *)d.copy;
     P.xv = d.xv + (size_t)v * 2 * N; P.zv = d.zv + (size_t)v * 2 * N; P.yv = d.yv + v;
     P.rho = d.cb->rho; P.mu_scale = d.cb->mu_scale; P.eps_edge = d.eps_edge; P.ipm_tol = d.ipm_tol; P.ipm_max_iter = d.ipm_max_iter;
+    P.warm = d.rec ? d.rec + d.rec_off[ti] : nullptr;
     TermExec ex{red};
     // work arrays: LDS when the launch was given room for the larger of the terminals (d.lds_doubles), the HBM workspace otherwise
     int r;
@@ -105,6 +106,7 @@ extern "C" int gcsadmm_debug_term_cycles(unsigned long long *cycles32, unsigned 
 #endif
 
 long long gcsadmm_terminal_ws_doubles(int n, int facets, int live_edges) { return gcs_term::terminal_ws_doubles(n, facets, live_edges); }
+long long gcsadmm_terminal_record_doubles(int n, int facets, int live_edges) { return gcs_term::terminal_record_doubles(n, facets, live_edges); }
 
 void gcsadmm_terminal_launch(const gcsadmm_k::TermLaunchDesc &d, hipStream_t s)
 {

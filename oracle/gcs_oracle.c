@@ -527,7 +527,7 @@ static int gauss_solve(int N, double *M, int ld, double *x)
     return 0;
 }
 static int solve_terminal_region(int n, int m, const double *A, const double *b, const double *cen, int d, int d_in, int is_src,
-                                 const double *T, double rho, const oracle_inner_params *ip, double *copy, double *xv, double *zv, double *yv)
+                                 const double *T, double rho, const oracle_inner_params *ip, double *copy, double *xv, double *zv, double *yv, double *warm)
 {
     const int NW = 2 * n + 1, R = 2 * m, q = n + 1, NF = n + 1, ldq = MAXN + 1;
     const int lo = is_src ? d_in : 0, hi = is_src ? d : d_in, L = hi - lo;
@@ -556,14 +556,52 @@ static int solve_terminal_region(int n, int m, const double *A, const double *b,
             tg[k] = is_src ? TW(k, ge) : TW(n + k, ge);     /* target of [O]_1 */
             tg[n + k] = is_src ? TW(n + k, ge) : 0.0;       /* target of [O]_2 (outgoing only) */
             qd[k] = rho; qd[n + k] = is_src ? rho : 0.0;
-            p[k] = cen[k] / L; p[n + k] = cen[k] / L;
         }
-        tg[2 * n] = TW(2 * n, ge); qd[2 * n] = rho; p[2 * n] = 1.0 / L;
+        tg[2 * n] = TW(2 * n, ge); qd[2 * n] = rho;
+    }
+    /* warm start, the rule of the vertex programs (WS_*, see the head of this file) with a fixed threshold.  Record of a terminal:
+     *   [0] valid [1] rho [2] live blocks [3] nu | per live block: p (NW) | targets (NW) | row duals (R)
+     * (t and the cone's dual are re-centred at the restart: not kept).  It fits the record every vertex has (oracle_warm_doubles). */
+    const int W_HDR = 4, W_PER = 2 * NW + R;
+    int use_warm = 0, it_total = 0;
+    double mu_ref = WS_COLD_REF;
+    if (warm && warm[0] == 1.0 && warm[1] == rho && (int)warm[2] == L) {
+        double dT = 0;
+        for (int e = 0; e < L; ++e) {
+            const double *w = warm + W_HDR + (size_t)e * W_PER + NW, *tg = Ttg(e), *qd = Tqd(e);
+            for (int k = 0; k < NW; ++k) if (qd[k] > 0) dT = fmax(dT, fabs(tg[k] - w[k]));
+        }
+        dT *= rho;
+        if (dT <= WS_COLD_DT) { use_warm = 1; mu_ref = fmax(WS_MU_MIN, WS_KAPPA * dT); }
     }
     double t = 1.0, nu = 0.0, ssoc[MAXN + 1], lsoc[MAXN + 1] = {0}, ksoc[MAXN + 1], dssoc[MAXN + 1], dlsoc[MAXN + 1];
     const int deg = L * R + 1;
-    int status = -1, it, stalled = 0;
+    int status, it, stalled, saved;
+terminal_restart:
+    status = -1; stalled = 0; saved = 0;
+    for (int k = 0; k < q; ++k) lsoc[k] = 0;
+    if (use_warm) {
+        double uu = 0, u[MAXN] = {0};
+        for (int e = 0; e < L; ++e) {
+            const double *w = warm + W_HDR + (size_t)e * W_PER;
+            memcpy(Tp(e), w, sizeof(double) * NW); memcpy(Tlam(e), w + 2 * NW, sizeof(double) * R);
+            for (int k = 0; k < n; ++k) u[k] += w[k] - w[n + k];
+        }
+        nu = warm[3];
+        for (int k = 0; k < n; ++k) uu += u[k] * u[k];
+        t = 0.5 * (mu_ref + sqrt(mu_ref * mu_ref + 4.0 * uu));      /* cone pair re-centred at mu_ref: t^2 - mu_ref t - |u|^2 = 0 */
+        lsoc[0] = 1.0;
+        for (int k = 0; k < n; ++k) lsoc[1 + k] = -u[k] / t;
+    } else {
+        for (int e = 0; e < L; ++e) {
+            double *p = Tp(e);
+            for (int k = 0; k < n; ++k) { p[k] = cen[k] / L; p[n + k] = cen[k] / L; }
+            p[2 * n] = 1.0 / L;
+        }
+        t = 1.0; nu = 0.0; mu_ref = WS_COLD_REF;
+    }
     for (it = 0; it <= ip->ipm_max_iter; ++it) {
+        const int first_warm = use_warm && it == 0;       /* the re-centring Newton step of a warm solve */
         int interior = 1;
         double gap = 0;
         for (int k = 1; k < q; ++k) ssoc[k] = 0;
@@ -580,18 +618,29 @@ static int solve_terminal_region(int n, int m, const double *A, const double *b,
         }
         ssoc[0] = t;
         if (!interior || !soc_interior(q, ssoc)) { status = -3; break; }
-        if (it == 0) {
+        if (it == 0 && !use_warm) {
             for (int e = 0; e < L; ++e) for (int r = 0; r < R; ++r) Tlam(e)[r] = 1.0 / Ts(e)[r];
             lsoc[0] = 1.0 / t;
         }
         for (int e = 0; e < L; ++e) for (int r = 0; r < R; ++r) gap += Ts(e)[r] * Tlam(e)[r];
         for (int k = 0; k < q; ++k) gap += ssoc[k] * lsoc[k];
         const double mu = gap / deg;
-        if (mu <= ip->ipm_tol || (stalled && mu <= 1e3 * ip->ipm_tol)) { status = 0; break; }
+        if (warm && !saved && it >= 1 && mu <= WS_SAVE * mu_ref) {      /* the record the next solve of this terminal restarts from */
+            saved = 1;
+            warm[0] = 1.0; warm[1] = rho; warm[2] = (double)L; warm[3] = nu;
+            for (int e = 0; e < L; ++e) {
+                double *w = warm + W_HDR + (size_t)e * W_PER;
+                memcpy(w, Tp(e), sizeof(double) * NW); memcpy(w + NW, Ttg(e), sizeof(double) * NW); memcpy(w + 2 * NW, Tlam(e), sizeof(double) * R);
+            }
+        }
+        if (!first_warm && (mu <= ip->ipm_tol || (stalled && mu <= 1e3 * ip->ipm_tol))) {
+            status = (use_warm && !(mu <= ip->ipm_tol)) ? -7 : 0;       /* (a warm solve does not leave through the precision-exhausted rule) */
+            break;
+        }
         if (it == ip->ipm_max_iter) break;
         /* scalings */
         double Wsoc[(MAXN + 1) * (MAXN + 1)], Wsoci[(MAXN + 1) * (MAXN + 1)], W2[(MAXN + 1) * (MAXN + 1)], wb[MAXN + 1], eta, lt[MAXN + 1];
-        if (soc_scaling(q, ssoc, lsoc, Wsoc, Wsoci, wb, &eta)) { status = mu <= 1e3 * ip->ipm_tol ? 0 : -4; break; }
+        if (soc_scaling(q, ssoc, lsoc, Wsoc, Wsoci, wb, &eta)) { status = (mu <= 1e3 * ip->ipm_tol && !use_warm) ? 0 : -4; break; }
         for (int i = 0; i < q; ++i)
             for (int j = 0; j < q; ++j) { double a = 0; for (int k = 0; k < q; ++k) a += Wsoci[i * ldq + k] * Wsoci[k * ldq + j]; W2[i * ldq + j] = a; }
         for (int i = 0; i < q; ++i) { double a = 0; for (int k = 0; k < q; ++k) a += Wsoc[i * ldq + k] * lsoc[k]; lt[i] = a; }
@@ -670,10 +719,12 @@ static int solve_terminal_region(int n, int m, const double *A, const double *b,
             { double a = -gt; for (int k = 0; k < n; ++k) a -= cv[k] * dssoc[1 + k]; dt = a / c0; }                              \
             dssoc[0] = dt;                                                                                                       \
         } while (0)
-        /* predictor */
-        double amax = 1e300, c1 = 0, c2 = 0;
+        /* predictor (the first iteration of a warm solve has none: kappa = mu_ref / s, no second-order term) */
+        double amax = 1e300, c1 = 0, c2 = 0, sm;
         for (int e = 0; e < L; ++e) memset(Tkap(e), 0, sizeof(double) * R);
-        for (int k = 0; k < q; ++k) ksoc[k] = 0;
+        for (int k = 0; k < q; ++k) { ksoc[k] = 0; dssoc[k] = 0; dlsoc[k] = 0; }
+        if (first_warm) sm = mu_ref;
+        else {
         TERMINAL_NEWTON();
         for (int e = 0; e < L; ++e) {
             double *s = Ts(e), *lam = Tlam(e), *ds = Tds(e), *dl = Tdl(e), *kap = Tkap(e);
@@ -685,14 +736,15 @@ static int solve_terminal_region(int n, int m, const double *A, const double *b,
         const double al_aff = fmin(1.0, amax);
         double sig = (gap + al_aff * c1 + al_aff * al_aff * c2) / deg / mu;
         sig = sig < 0 ? 0 : (sig > 1 ? 1 : sig); sig = sig * sig * sig;
-        const double sm = sig * mu;
+        sm = sig * mu;
+        }
         /* corrector multipliers */
         for (int e = 0; e < L; ++e) { double *kap = Tkap(e); const double *s = Ts(e); for (int r = 0; r < R; ++r) kap[r] = (sm - kap[r]) / s[r]; }
         {
             double a1[MAXN + 1], a2[MAXN + 1], pr[MAXN + 1], qv[MAXN + 1];
             for (int i = 0; i < q; ++i) {
                 double u1 = 0, u2 = 0;
-                for (int k = 0; k < q; ++k) { u1 += Wsoci[i * ldq + k] * dssoc[k]; u2 += Wsoc[i * ldq + k] * dlsoc[k]; }
+                for (int k = 0; k < q && !first_warm; ++k) { u1 += Wsoci[i * ldq + k] * dssoc[k]; u2 += Wsoc[i * ldq + k] * dlsoc[k]; }
                 a1[i] = u1; a2[i] = u2;
             }
             soc_prod(q, a1, a2, pr);
@@ -729,6 +781,9 @@ static int solve_terminal_region(int n, int m, const double *A, const double *b,
         for (int k = 0; k < q; ++k) lsoc[k] += al * dlsoc[k];
     }
 terminal_done:
+    it_total += it;
+    if (status != 0 && warm) warm[0] = 0.0;                                     /* no restart from a solve that failed */
+    if (status != 0 && use_warm) { use_warm = 0; goto terminal_restart; }        /* a failed warm solve is repeated cold */
     if (status != 0) return status < -1 ? status : -1;
     for (int k = 0; k < 2 * n; ++k) xv[k] = 0;
     for (int e = 0; e < d; ++e) {
@@ -743,7 +798,7 @@ terminal_done:
     }
     for (int k = 0; k < 2 * n; ++k) zv[k] = xv[k];
     *yv = 1.0;
-    return it;
+    return it_total;
 }
 
 int oracle_solve_vertex(int n, int m, const double *A, const double *b_raw, const double *cen,
@@ -753,7 +808,7 @@ int oracle_solve_vertex(int n, int m, const double *A, const double *b_raw, cons
     const int NW = 2 * n + 1, NX = 2 * n, NB = 4 * n + 2, q = n + 1, c = 2 * n + 1;
     const int d_out = d - d_in;
     if ((is_src || is_dst) && terminal_extent(n, m, A, b_raw, cen) > 1e-5)
-        return solve_terminal_region(n, m, A, b_raw, cen, d, d_in, is_src, T, rho, ip, copy, xv, zv, yv);
+        return solve_terminal_region(n, m, A, b_raw, cen, d, d_in, is_src, T, rho, ip, copy, xv, zv, yv, warm);
     if (is_src || is_dst) {
         /* point vertex (box of half-width 1e-6 around cen): O_{e,i} = y_e * pt on the live side,
          * sum y_e = 1 -> separable quadratic over the simplex; the other side is dead (y = 0). */

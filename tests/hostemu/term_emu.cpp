@@ -18,7 +18,7 @@ struct HostExec {
 
 template <int N>
 int run(int m, const double *A, const double *b_raw, const double *cen, int d, int d_in, int is_src, const double *T, double rho,
-        double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv, double *zv, double *yv)
+        double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv, double *zv, double *yv, double *warm)
 {
     std::vector<double> bc(m), zero((size_t)(2 * N + 1) * d, 0.0);
     std::vector<int> edges(d);
@@ -28,7 +28,7 @@ int run(int m, const double *A, const double *b_raw, const double *cen, int d, i
     P.m = m; P.d = d; P.d_in = d_in; P.is_src = is_src; P.A = A; P.bc = bc.data(); P.cen = cen;
     P.inc_edge = edges.data(); P.inc_lo = 0; P.E = d; P.NI = d; P.edge_major = 0;
     P.zedge = T; P.mu = zero.data(); P.copy = copy; P.xv = xv; P.zv = zv; P.yv = yv;
-    P.rho = rho; P.mu_scale = 0.0; P.eps_edge = eps_edge; P.ipm_tol = ipm_tol; P.ipm_max_iter = ipm_max_iter;
+    P.rho = rho; P.mu_scale = 0.0; P.eps_edge = eps_edge; P.ipm_tol = ipm_tol; P.ipm_max_iter = ipm_max_iter; P.warm = warm;
     const int L = is_src ? d - d_in : d_in;
     std::vector<double> ws((size_t)gcs_term::terminal_ws_doubles(N, m, L > 0 ? L : 1), NAN);      // unwritten workspace is poisoned
     gcs_term::TermShared<N> sh;
@@ -39,13 +39,16 @@ int run(int m, const double *A, const double *b_raw, const double *cen, int d, i
 
 extern "C" int term_emu_solve(int n, int m, const double *A, const double *b_raw, const double *cen, int d, int d_in, int is_src,
                               const double *T, double rho, double eps_edge, double ipm_tol, int ipm_max_iter, double *copy, double *xv,
-                              double *zv, double *yv)
+                              double *zv, double *yv, double *warm)
 {
     switch (n) {
-    case 1: return run<1>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv);
-    case 2: return run<2>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv);
-    case 3: return run<3>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv);
-    case 6: return run<6>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv);
+    case 1: return run<1>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
+    case 2: return run<2>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
+    case 3: return run<3>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
+    case 6: return run<6>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
     default: return -100;
     }
 }
+
+// doubles of a terminal's warm-start record (zeroed by the caller: no record yet)
+extern "C" long long term_emu_record_doubles(int n, int m, int live) { return gcs_term::terminal_record_doubles(n, m, live); }

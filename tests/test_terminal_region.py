@@ -23,12 +23,13 @@ def polygon(rng, m, centre, radius):
     return A, b
 
 
-def oracle_terminal(n, A, b, cen, d, d_in, is_src, T, rho, tol=IPM_TOL):
+def oracle_terminal(n, A, b, cen, d, d_in, is_src, T, rho, tol=IPM_TOL, warm=None):
+    """warm: the vertex's warm-start record (oracle_warm_doubles doubles, zero = none yet), None = cold"""
     lib = O.lib()
     ip = O._Inner(1e-4, tol, 60, None, None)
     copy = np.zeros((2 * n + 1, d)); xv = np.zeros(2 * n); zv = np.zeros(2 * n); yv = np.zeros(1)
     r = lib.oracle_solve_vertex(n, A.shape[0], _p(A), _p(b), _p(cen), d, d_in, int(is_src), int(not is_src), _p(T), C.c_double(rho),
-                                C.byref(ip), _p(copy), _p(xv), _p(zv), _p(yv), None)
+                                C.byref(ip), _p(copy), _p(xv), _p(zv), _p(yv), _p(warm) if warm is not None else None)
     assert r >= 0, r
     return copy, xv, zv, yv[0], r
 
@@ -176,10 +177,10 @@ def term_emu():
     return C.CDLL(out)
 
 
-def emu_terminal(lib, n, A, b, cen, d, d_in, is_src, T, rho, tol=IPM_TOL):
+def emu_terminal(lib, n, A, b, cen, d, d_in, is_src, T, rho, tol=IPM_TOL, warm=None):
     copy = np.full((2 * n + 1, d), np.nan); xv = np.zeros(2 * n); zv = np.zeros(2 * n); yv = np.zeros(1)
     r = lib.term_emu_solve(n, A.shape[0], _p(A), _p(b), _p(cen), d, d_in, int(is_src), _p(T), C.c_double(rho), C.c_double(1e-4),
-                           C.c_double(tol), 60, _p(copy), _p(xv), _p(zv), _p(yv))
+                           C.c_double(tol), 60, _p(copy), _p(xv), _p(zv), _p(yv), _p(warm) if warm is not None else None)
     assert r >= 0, r
     return copy, xv, zv, yv[0], r
 
@@ -210,3 +211,38 @@ def test_device_body_of_the_terminal_solve_matches_the_oracle(term_emu, n, seed)
     assert not np.isnan(e[0]).any()
     assert np.abs(a[0] - e[0]).max() < 2e-5 and np.abs(a[1] - e[1]).max() < 2e-5 and e[3] == 1.0
     assert np.array_equal(e[1], e[2])
+
+
+@pytest.mark.parametrize("n,seed", [(2, 0), (2, 1), (3, 2), (6, 3)])
+def test_warm_started_terminal_solves(term_emu, n, seed):
+    """a sequence of solves whose targets drift (as along an ADMM run), each restarted from the record the previous one left: oracle and
+    device body agree with each other, and both with a cold solve of the same sub-problem; the warm solves need fewer iterations"""
+    rng = np.random.default_rng(200 + seed)
+    is_src = seed % 2 == 0
+    cen = rng.uniform(-1, 1, n)
+    A, b = polygon(rng, 4 + seed % 3, cen, 0.6) if n == 2 else box_in(rng, n, cen, 0.5)
+    d_in, d_out = 2, 3
+    d, L = d_in + d_out, (d_out if is_src else d_in)
+    rho = [0.5, 2.0][seed % 2]
+    T = np.zeros((2 * n + 1, d))
+    T[0:2 * n] = np.tile(cen, 2)[:, None] * 0.4 + 0.35 * rng.normal(size=(2 * n, d))
+    T[2 * n] = rng.uniform(-0.1, 0.8, d)
+    O.lib().oracle_warm_doubles.restype = C.c_longlong
+    term_emu.term_emu_record_doubles.restype = C.c_longlong
+    wo = np.zeros(O.lib().oracle_warm_doubles(n, A.shape[0], d))
+    we = np.zeros(term_emu.term_emu_record_doubles(n, A.shape[0], L))
+    assert 4 + L * (2 * (2 * n + 1) + 2 * A.shape[0]) == len(we) <= len(wo)
+    cold_its, warm_its = [], []
+    for step in range(12):
+        if step:
+            T = T + (0.02 if step < 8 else 0.3) * rng.normal(size=T.shape) * (np.arange(2 * n + 1)[:, None] >= 0)
+        c = oracle_terminal(n, A, b, cen, d, d_in, is_src, T, rho)
+        a = oracle_terminal(n, A, b, cen, d, d_in, is_src, T, rho, warm=wo)
+        e = emu_terminal(term_emu, n, A, b, cen, d, d_in, is_src, T, rho, warm=we)
+        assert np.abs(a[0] - e[0]).max() < 2e-5, (step, np.abs(a[0] - e[0]).max())
+        assert step >= 8 or abs(a[4] - e[4]) <= 1, (step, a[4], e[4])      # (large moves sit at the warm / cold threshold: the two may decide differently)
+        assert np.abs(a[0] - c[0]).max() < 2e-3, (step, np.abs(a[0] - c[0]).max())        # the fixtures' bound between two solves of one sub-problem
+        assert wo[0] == 1.0 and we[0] == 1.0 and np.abs(wo[4:4 + len(we) - 4] - we[4:]).max() < 1e-4      # same record, same layout
+        cold_its.append(c[4]); warm_its.append(a[4])
+    assert warm_its[0] == cold_its[0]                                   # no record yet: cold
+    assert np.mean(warm_its[1:8]) <= np.mean(cold_its[1:8]) - 2         # small moves: the restart pays
