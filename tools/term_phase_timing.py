@@ -1,4 +1,4 @@
-"""Diagnostic: ticks (s_memtime, 100 MHz) per phase of the region-terminal solve (csrc/terminal_region.h), workgroup 0, from the timing build
+"""Diagnostic: s_memtime ticks (shader clock, ~2.4 GHz on this part: 35 k ticks = 15 us) per phase of the region-terminal solve (csrc/terminal_region.h), workgroup 0, from the timing build
 (python -m gcs_admm_amd.build --timing).   python3 tools/term_phase_timing.py"""
 import ctypes as C, os, sys
 import numpy as np
@@ -26,7 +26,7 @@ cyc = (C.c_ulonglong * 32)(); cnt = (C.c_ulonglong * 32)()
 assert d.lib.gcsadmm_debug_term_cycles(cyc, cnt) == 0
 c, n = np.array(list(cyc), float), np.array(list(cnt), float)
 tot = c.sum()
-print(f"{steps} solves of terminal 0: {tot / steps:.0f} ticks per solve ({tot / steps / 100:.1f} us), {n[0] / steps:.1f} Newton iterations + the final stop test")
+print(f"{steps} solves of terminal 0: {tot / steps:.0f} ticks per solve, {n[0] / steps:.1f} Newton iterations + the final stop test")
 for k in sorted(NAMES):
     if n[k] > 0:
         print(f"  {k:2d} {NAMES[k]:40s} {100 * c[k] / tot:5.1f} %   {c[k] / n[k]:7.1f} ticks/visit  x{n[k] / steps:.1f} per solve")
