@@ -1,7 +1,8 @@
 """Soak of tests/test_gpu_parity.py::test_random_scenes_fuzz over many seeds: random polygon scenes, random penalty, the vertex step of
 the device against the oracle's from random (unreachable) states.  Prints the distribution of the worst entry per step and counts
 steps above the test's 2e-3 bound (round 3, before a warm solve was barred from the precision-exhausted exit: 5 of 1 920 steps above it,
-worst 6.9e-3).   python tools/fuzz_soak.py [seeds] [program] [first seed]"""
+worst 6.9e-3).   python tools/fuzz_soak.py [seeds] [program] [first seed] [regions]
+("regions": the terminals are boxes of half-width 0.1 .. 0.5 about the points they were -- the region-terminal kernel, csrc/terminal_region.h)"""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,11 +17,19 @@ from scale_demo import polygon_scene
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 program = sys.argv[2] if len(sys.argv) > 2 else "auto"
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+regions = len(sys.argv) > 4 and sys.argv[4] == "regions"
+term_worst = []
 worst, fails, above = [], 0, []
 for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(100 + seed)
     As, bs = polygon_scene(5 + seed % 3, seed=seed, m=3 + seed % 5)
+    if regions:
+        Abox = np.vstack([np.eye(2), -np.eye(2)])
+        for key in ("s", "t"):
+            pt = 0.5 * (bs[key][:2] - bs[key][2:]); half = rng.uniform(0.1, 0.5)
+            As[key], bs[key] = Abox, np.hstack([pt + half, -pt + half])
     g = graph_from_sets(As, bs, 2)
+    tcols = np.concatenate([np.arange(g.inc_ptr[v], g.inc_ptr[v + 1]) for v in (g.src, g.dst)])
     o = Oracle(g, ipm_tol=IPM_TOL)
     d = DeviceSolver(g, "f64", device=0, program=program)
     rho = float([0.25, 1.0, 4.0][seed % 3])
@@ -32,11 +41,12 @@ for seed in range(first, first + n_seeds):
         d.vertex_step()
         fails += int(o.vertex_step(rho, 1.0) != 0)
         diff = np.abs(d.copy.cpu().numpy() - o.copy)
-        worst.append(float(diff.max()))
+        worst.append(float(diff.max())); term_worst.append(float(diff[:, tcols].max()))
         if diff.max() > 2e-3:
             above.append((seed, it, float(diff.max())))
         o.edge_step(1.0)
     d.close()
 w = np.array(worst)
 print(json.dumps({"program": program, "first_seed": first, "scenes": n_seeds, "steps": len(w), "oracle_failures": fails, "worst_entry": {"max": float(w.max()), "p99": float(np.quantile(w, 0.99)),
-                  "median": float(np.median(w))}, "steps_above_2e-3": above}))
+                  "median": float(np.median(w))}, "steps_above_2e-3": above,
+                  "terminal_columns_worst": {"max": float(np.max(term_worst)), "p99": float(np.quantile(term_worst, 0.99)), "median": float(np.median(term_worst))}, "region_terminals": regions}))
