@@ -608,7 +608,9 @@ template <class T> static gcsadmm_status launch_edge(gcsadmm_handle h, const gcs
         case 7: GCS_EDGE(7); break;
         case 9: GCS_EDGE(9); break;
         case 11: GCS_EDGE(11); break;
-        default: GCS_EDGE(13);
+        case 13: GCS_EDGE(13); break;
+        case 15: GCS_EDGE(15); break;
+        default: GCS_EDGE(17);          // n = 8 (gcsadmm_create admits n = 1 .. 8)
         }
 #undef GCS_EDGE_U
 #undef GCS_EDGE
@@ -815,7 +817,7 @@ gcsadmm_status gcsadmm_create(const gcsadmm_graph_desc *g, gcsadmm_handle *out)
     if (out) *out = nullptr;
     auto fail = [&](gcsadmm_status st, const std::string &msg) { g_create_error = msg; return st; };
     if (!g || !out) return fail(GCSADMM_ERR_BAD_ARG, "null descriptor or output pointer");
-    if (g->n < 1 || g->n > 6) return fail(GCSADMM_ERR_UNSUPPORTED, "the vertex kernels are instantiated for n = 1 .. 6");
+    if (g->n < 1 || g->n > 8) return fail(GCSADMM_ERR_UNSUPPORTED, "the vertex kernels are instantiated for n = 1 .. 8");
     if (g->num_vertices < 0 || g->num_edges < 0) return fail(GCSADMM_ERR_BAD_ARG, "negative size");
     if (!g->inc_ptr || !g->poly_ptr || (g->num_edges > 0 && (!g->inc_edge || !g->inc_out || !g->edge_inc_tail || !g->edge_inc_head)) ||
         (g->num_vertices > 0 && (!g->poly_A || !g->poly_b || !g->center)))

@@ -102,7 +102,7 @@ struct Scene {
 
 static int upload_scene(Scene &sc, int n, int P, const int *poly_ptr, const double *A, const double *b, int device)
 {
-    if (n < 1 || n > 6) { g_err = "polytope LPs are instantiated for n = 1..6"; return GCSADMM_ERR_UNSUPPORTED; }
+    if (n < 1 || n > 8) { g_err = "polytope LPs are instantiated for n = 1..8"; return GCSADMM_ERR_UNSUPPORTED; }
     if (P < 0 || !poly_ptr || (P > 0 && (!A || !b))) { g_err = "null polytope array"; return GCSADMM_ERR_BAD_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device"; return GCSADMM_ERR_NO_DEVICE; }
@@ -170,7 +170,9 @@ static int launch_bounds(const Scene &sc, const double *d_centers, double *d_lo,
     case 3: { constexpr int NN = 3; rc = CALL; } break;                                                \
     case 4: { constexpr int NN = 4; rc = CALL; } break;                                                \
     case 5: { constexpr int NN = 5; rc = CALL; } break;                                                \
-    default: { constexpr int NN = 6; rc = CALL; } break;                                               \
+    case 6: { constexpr int NN = 6; rc = CALL; } break;                                                \
+    case 7: { constexpr int NN = 7; rc = CALL; } break;                                                \
+    default: { constexpr int NN = 8; rc = CALL; } break;                                               \
     }
 
 } // namespace gcsadmm_lp

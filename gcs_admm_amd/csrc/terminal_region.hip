@@ -119,6 +119,8 @@ void gcsadmm_terminal_launch(const gcsadmm_k::TermLaunchDesc &d, hipStream_t s)
     case 4: launch_n<4>(d, s); break;
     case 5: launch_n<5>(d, s); break;
     case 6: launch_n<6>(d, s); break;
+    case 7: launch_n<7>(d, s); break;
+    case 8: launch_n<8>(d, s); break;
     default: break;
     }
 }

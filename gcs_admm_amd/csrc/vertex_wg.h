@@ -220,7 +220,7 @@ template <int N> struct WLBox {
 template <int N> GCS_HD int wg_lds_doubles(int U, int m, bool box = false) { return box ? WLBox<N>::total(U, m) : WL<N>::total(U, m); }
 // the program is dimension-generic (admm_solver_v3.py:363-377 takes any n): instantiated for n = 1 .. 6; the BOX instantiation and
 // its layout exist for the two dimensions that are tuned for it, n = 3 and 6
-constexpr int WG_MAX_N = 6;
+constexpr int WG_MAX_N = 8;
 inline bool wg_has_box(int n) { return n == 3 || n == 6; }
 inline int wg_lds_doubles_n(int n, int U, int m, bool box = false)
 {
@@ -231,7 +231,9 @@ inline int wg_lds_doubles_n(int n, int U, int m, bool box = false)
     case 3: return wg_lds_doubles<3>(U, m, box);
     case 4: return wg_lds_doubles<4>(U, m);
     case 5: return wg_lds_doubles<5>(U, m);
-    default: return wg_lds_doubles<6>(U, m, box);
+    case 6: return wg_lds_doubles<6>(U, m, box);
+    case 7: return wg_lds_doubles<7>(U, m);
+    default: return wg_lds_doubles<8>(U, m);
     }
 }
 

@@ -15,7 +15,7 @@ using namespace gcsadmm_k;
 #define GCS_WG_SYM(name) name
 #endif
 
-// n = 1, 4, 5 (vertex_wg_dims.hip, the object of the same thread count)
+// n = 1, 4, 5, 7, 8 (vertex_wg_dims.hip, the object of the same thread count)
 hipError_t GCS_WG_SYM(gcsadmm_wg_set_lds_dims)(int n, int dtype, int lds_bytes);
 void GCS_WG_SYM(gcsadmm_wg_launch_dims)(const WgLaunchDesc &d, hipStream_t s);
 void GCS_WG_SYM(gcsadmm_wg_launch_prox_dims)(const WgLaunchDesc &d, const double *q, const double *c, int src, int dst, hipStream_t s);

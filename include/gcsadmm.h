@@ -53,7 +53,7 @@ enum { GCSADMM_F64 = 0, GCSADMM_F32 = 1 };
 enum { GCSADMM_RUNNING = -1, GCSADMM_CONVERGED = 0, GCSADMM_MAX_IT = 1, GCSADMM_DIVERGED = 2 };
 
 typedef struct gcsadmm_graph_desc {
-    int32_t n;                       /* space dimension: 1 .. 6 */
+    int32_t n;                       /* space dimension: 1 .. 8 */
     int32_t num_vertices;            /* vertices whose sub-problem this handle solves */
     int32_t num_edges;               /* directed edges this handle updates */
     int32_t num_incidences;          /* NI: columns of copy/mu; >= inc_ptr[num_vertices]; the surplus are

@@ -29,6 +29,8 @@ extern "C" int lp_emu_ball(int n, int P, const int *ptr, const double *A, const 
     case 4: return centre<4>(S, p, q, x0, w_out, early, tol, iters);
     case 5: return centre<5>(S, p, q, x0, w_out, early, tol, iters);
     case 6: return centre<6>(S, p, q, x0, w_out, early, tol, iters);
+    case 7: return centre<7>(S, p, q, x0, w_out, early, tol, iters);
+    case 8: return centre<8>(S, p, q, x0, w_out, early, tol, iters);
     }
     return -99;
 }

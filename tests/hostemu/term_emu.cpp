@@ -46,6 +46,7 @@ extern "C" int term_emu_solve(int n, int m, const double *A, const double *b_raw
     case 2: return run<2>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
     case 3: return run<3>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
     case 6: return run<6>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
+    case 8: return run<8>(m, A, b_raw, cen, d, d_in, is_src, T, rho, eps_edge, ipm_tol, ipm_max_iter, copy, xv, zv, yv, warm);
     default: return -100;
     }
 }

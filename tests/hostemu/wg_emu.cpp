@@ -88,7 +88,9 @@ extern "C" int EMU_FN(int n, int V, int E, int NI, const int *inc_ptr, const int
     case 3: run_all<3>(a, rho, mu_scale, lds, status, iters); break;
     case 4: run_all<4>(a, rho, mu_scale, lds, status, iters); break;
     case 5: run_all<5>(a, rho, mu_scale, lds, status, iters); break;
-    default: run_all<6>(a, rho, mu_scale, lds, status, iters);
+    case 6: run_all<6>(a, rho, mu_scale, lds, status, iters); break;
+    case 7: run_all<7>(a, rho, mu_scale, lds, status, iters); break;
+    default: run_all<8>(a, rho, mu_scale, lds, status, iters);
     }
     return 0;
 }

@@ -510,7 +510,7 @@ def test_workgroup_box_instantiation_against_generic(torch_gpu, n):
     assert float(a.copy.abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("case", ["benchmark4", "lattice_n3", "lattice_n6", "lattice_n4"])
+@pytest.mark.parametrize("case", ["benchmark4", "lattice_n3", "lattice_n6", "lattice_n4", "lattice_n8"])
 def test_workgroup_512_threads_against_256(torch_gpu, case):
     """launches of at most one workgroup per CU run the 512-thread build of the workgroup program (second object of vertex_wg.hip,
     chosen at create); vertex_program = 3 keeps 256.  Same tasks on more threads: cold runs agree to rounding (the reductions sum in
@@ -520,7 +520,8 @@ def test_workgroup_512_threads_against_256(torch_gpu, case):
     from gcs_admm_amd.solver import DeviceSolver
     g, dt = {"benchmark4": (lambda: load_fixture("benchmark4")[1], "f64"), "lattice_n3": (lambda: lattice_boxes(9, 8, n=3, seed=4), "f64"),
              "lattice_n6": (lambda: lattice_boxes(7, 6, n=6, seed=2), "f32"),
-             "lattice_n4": (lambda: lattice_boxes(8, 7, n=4, seed=5), "f64")}[case]     # (n = 1, 4, 5: the second object of vertex_wg_dims.hip)
+             "lattice_n4": (lambda: lattice_boxes(8, 7, n=4, seed=5), "f64"),     # (n = 1, 4, 5, 7, 8: the second object of vertex_wg_dims.hip)
+             "lattice_n8": (lambda: lattice_boxes(6, 5, n=8, seed=6), "f64")}[case]
     g = g()
     a = DeviceSolver(g, dt, device=0, program="workgroup")
     b = DeviceSolver(g, dt, device=0, program="workgroup256")

@@ -213,10 +213,10 @@ def test_partitioned_handles_match_single(torch_gpu):
         assert np.allclose(d.zedge.cpu().numpy(), full[:, p.edge_global], rtol=0, atol=5e-4)
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 5, 6])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 6, 7, 8])
 def test_other_space_dimensions(torch_gpu, oracle_lib, n):
     """The sub-problem takes any space dimension (admm_solver_v3.py:363-377); BASELINE config 5 is a GCS in R^6.  The workgroup
-    program instantiated for n = 1 .. 6 (n = 2 has its own tests) against the oracle, step by step and over a short run: box
+    program instantiated for n = 1 .. 8 (n = 2 has its own tests; 7, 8 since round 4) against the oracle, step by step and over a short run: box
     lattices, and a chain of intervals for n = 1."""
     torch = torch_gpu
     if n == 1:

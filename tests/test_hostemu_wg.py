@@ -66,7 +66,8 @@ def wg_step(lib, fn, g, zedge, mu, rho=1.0, mu_scale=1.0, max_iter=60, warm=None
 CASES = [("benchmark1", None, 12, 2e-3), ("benchmark4", None, 12, 2e-3), ("test_autogen2", None, 8, 2e-3),
          ("lattice n=2", (5, 4, 2), 8, 1e-6), ("lattice n=3", (4, 3, 3), 6, 1e-6), ("lattice n=6", (4, 3, 6), 5, 1e-6),
          # the program is dimension-generic (admm_solver_v3.py:363-377 takes any n): the instantiations outside BASELINE's configs
-         ("intervals n=1", "chain", 8, 1e-6), ("lattice n=4", (4, 3, 4), 5, 1e-6), ("lattice n=5", (4, 3, 5), 5, 1e-6)]
+         ("intervals n=1", "chain", 8, 1e-6), ("lattice n=4", (4, 3, 4), 5, 1e-6), ("lattice n=5", (4, 3, 5), 5, 1e-6),
+         ("lattice n=7", (4, 3, 7), 4, 1e-6), ("lattice n=8", (4, 3, 8), 4, 1e-6)]
 
 
 @pytest.mark.parametrize("name,lat,steps,tol", CASES)

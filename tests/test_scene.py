@@ -74,7 +74,7 @@ def test_device_graph_matches_fixture(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 3, 6])
+@pytest.mark.parametrize("n", [2, 3, 6, 8])
 def test_device_overlaps_random_polytopes(n):
     """pairwise decisions on random polytopes equal the oracle's wherever the decision has a margin"""
     from gcs_admm_amd.scene import PolytopeScene
@@ -143,8 +143,8 @@ def test_device_graph_lattice_at_scale():
 def test_device_lp_errors():
     from gcs_admm_amd.scene import PolytopeScene
     from gcs_admm_amd.solver import GcsAdmmError
-    A = np.vstack([np.eye(7), -np.eye(7)]); b = np.ones(14)
-    with pytest.raises(GcsAdmmError, match="n = 1..6"):
+    A = np.vstack([np.eye(9), -np.eye(9)]); b = np.ones(18)
+    with pytest.raises(GcsAdmmError, match="n = 1..8"):
         PolytopeScene([(A, b)]).centers()
     A2 = np.vstack([np.eye(2), -np.eye(2)]); b2 = np.ones(4)
     with pytest.raises(GcsAdmmError, match="out of range"):
@@ -177,7 +177,7 @@ def _emu_ball(lib, polys, p, q, x0=None, early=0, tol=1e-9):
     return st, w, it.value
 
 
-@pytest.mark.parametrize("n", [2, 3, 6])
+@pytest.mark.parametrize("n", [2, 3, 6, 7])
 def test_lp_core_against_oracle_on_the_host(lp_emu, n):
     """the per-lane interior-point LP (host build of polytope_lp_core.h): Chebyshev radii and pairwise decisions
     equal the oracle's HiGHS LPs, also for regions hundreds of units from the origin and for the reference's
