@@ -378,15 +378,19 @@ def test_partitioned_loop_behind_the_abi_single_rank(torch_gpu):
     assert np.array_equal(a.zedge.cpu().numpy(), b.zedge.cpu().numpy())
 
 
-@pytest.mark.parametrize("columns", ["incidence", "edge"])
-def test_overlapped_partitioned_loop_equals_serial(torch_gpu, columns):
+@pytest.mark.parametrize("columns,terminals", [("incidence", "points"), ("edge", "points"), ("edge", "boxes")])
+def test_overlapped_partitioned_loop_equals_serial(torch_gpu, columns, terminals):
     """The overlapped schedule of gcsadmm_run_partitioned (boundary wavefronts first, the halo exchange on a second stream behind an
     event while the interior wavefronts are solved, the edge step waiting for both) against the serial one and against the plain
     loop: the same bits.  One rank (a real one-rank RCCL communicator), so the split is forced: the first quarter of the wavefronts
     plays the boundary -- the two launches, their slowest-first re-ordering inside each part (every eighth step), the second stream
-    and the two events are what is exercised; the exchange itself moves nothing here."""
+    and the two events are what is exercised; the exchange itself moves nothing here.  "boxes": the terminals are regions, their kernel
+    forks from and joins whichever stream carries the boundary part."""
     from gcs_admm_amd.solver import DeviceSolver
     g = lattice_boxes(40, 40, seed=3)
+    if terminals == "boxes":
+        for v in (g.src, g.dst):
+            g.poly_b[g.poly_ptr[v]:g.poly_ptr[v + 1]] += 0.3
     steps = 40
     out = {}
     for mode in ("plain", 2, 1):
