@@ -276,6 +276,57 @@ def test_region_terminals_vertex_step_against_oracle(torch_gpu, oracle_lib, prog
         d.close()
 
 
+def _region_star(n, spokes, seed=0):
+    """a source that is a big box in R^n overlapping `spokes` small boxes on a ring; the target a point in the last of them (edges given: no
+    |V|^2 overlap tests).  The source's sub-problem has `spokes` live blocks: at n = 6 its work arrays exceed the LDS budget of the terminal
+    kernel (HBM workspace, 256 threads), at n = 3 they fit (LDS, one wavefront for few rows)"""
+    from gcs_admm_amd.graph import convert_pt_to_polytope, graph_from_sets
+    rng = np.random.default_rng(seed)
+    A = np.vstack([np.eye(n), -np.eye(n)])
+    As, bs = {}, {}
+    As['s'], bs['s'] = A, np.hstack([np.full(n, 1.0), np.full(n, 1.0)])                      # [-1, 1]^n
+    edges = []
+    for k in range(spokes):
+        c = np.zeros(n); ang = 2 * np.pi * k / spokes
+        c[0], c[1] = 1.1 * np.cos(ang), 1.1 * np.sin(ang)
+        c[2:] = rng.uniform(-0.3, 0.3, n - 2)
+        h = rng.uniform(0.3, 0.4, n)
+        As[k], bs[k] = A, np.hstack([c + h, -c + h])
+        edges += [('s', k), (k, 's')]
+    last = spokes - 1
+    ctr = 0.5 * (bs[last][:n] - bs[last][n:])
+    As['t'], bs['t'] = convert_pt_to_polytope(ctr + 0.1)
+    edges += [(last, 't'), ('t', last)]
+    for k in range(spokes):                                                                   # neighbours on the ring overlap
+        edges += [(k, (k + 1) % spokes), ((k + 1) % spokes, k)]
+    keys = ['s', 't'] + list(range(spokes))
+    return graph_from_sets({k: As[k] for k in keys}, {k: bs[k] for k in keys}, n, edges=edges)
+
+
+@pytest.mark.parametrize("n,spokes", [(3, 8), (6, 30), (8, 6)])
+def test_region_terminal_other_dimensions_and_degrees(torch_gpu, oracle_lib, n, spokes):
+    """the terminal kernel outside n = 2: a source box with 8 live edges in R^3, 30 in R^6 (work arrays in the HBM workspace, 256 threads)
+    and 6 in R^8, vertex steps along an oracle run against the oracle"""
+    from oracle.oracle import Oracle
+    torch = torch_gpu
+    g = _region_star(n, spokes, seed=n)
+    assert int(np.diff(g.inc_ptr)[g.src]) == 2 * spokes
+    o = Oracle(g, ipm_tol=IPM_TOL)
+    d = _solver(g)
+    d.reset()
+    tcols = np.arange(g.inc_ptr[g.src], g.inc_ptr[g.src + 1])
+    for it in range(8):
+        d.zedge.copy_(torch.from_numpy(o.zedge)); d.mu.copy_(torch.from_numpy(o.mu))
+        d.vertex_step()
+        assert o.vertex_step(1.0, 1.0) == 0 and d.read_control().inner_failures == 0
+        got = d.copy.cpu().numpy()
+        assert np.abs(got[:, tcols] - o.copy[:, tcols]).max() < 1e-5, (it, np.abs(got[:, tcols] - o.copy[:, tcols]).max())
+        assert np.abs(got - o.copy).max() < 2e-3
+        assert abs(o.copy[2 * n, tcols[spokes:]].sum() - 1.0) < 1e-9 and d.yv[g.src].item() == 1.0      # the unit of flow leaves the source
+        o.edge_step(1.0)
+    d.close()
+
+
 def test_region_terminals_whole_run(torch_gpu, oracle_lib):
     """the loop with region terminals to the reference's stop rule: same stop iteration and residual trace as the oracle; on the row of
     three boxes the cost is the known answer (length 1 between the faces x = 1 and x = 2, + 2 edges x 1e-4), where point terminals at
