@@ -497,7 +497,10 @@ static void *ws_get(size_t bytes)
  *   min  t + sum_e [ eps y_e + rho/2 ( |[O_e]_1 - T1_e|^2 + out_e |[O_e]_2 - T2_e|^2 + (y_e - Ty_e)^2 ) ]
  *   s.t. A [O_e]_i <= y_e b  (i = 1, 2),   sum_e y_e = 1,   | sum_e ([O_e]_1 - [O_e]_2) | <= t.
  * (A point collapses this to the simplex projection above.)  Same primal-dual method as the generic vertex (Mehrotra, one step
- * length, NT scaling of the cone, sigma = (mu_aff / mu)^3, stop on mu), started cold every time from y_e = 1 / L, O_e = y_e (c, c).
+ * length, NT scaling of the cone, sigma = (mu_aff / mu)^3, stop on mu), started cold from y_e = 1 / L, O_e = y_e (c, c) or warm from the
+ * terminal's record (below).  PARITY UNPINNED by the reference's outputs: no record or fixture of the reference has a terminal with an extent;
+ * this restatement is pinned to the reference's formulation as written (tests/test_terminal_region.py: SLSQP on every variable and row of
+ * admm_solver_v3.py:352-466 with delta = 1).
  * The Hessian is block diagonal plus the cone and the equality through F = [I, -I, 0; 0, 0, 1]: blocks are eliminated onto
  * (du, dnu), n + 1 unknowns.  The HIP twin is csrc/terminal_region.h. */
 static double terminal_extent(int n, int m, const double *A, const double *b_raw, const double *cen)
